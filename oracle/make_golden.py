@@ -89,7 +89,9 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     dump_model_configs()
     dump_nn("tiny", 4, 11)
-    dump_nn("test_b4c64btl2", 4, 12)
-    dump_nn("test_b3c64nbt", 4, 13)
+    dump_nn("test_b3c128btl2", 3, 12)
+    dump_nn("test_b3c128nbt", 3, 13)
+    dump_nn("test_b3c256btl1", 3, 16)
+    dump_nn("test_b3c256nbt", 3, 17)
     dump_nn("b8c128nbt", 2, 14)
     dump_nn("b12c256btl3", 2, 15)

@@ -1,0 +1,590 @@
+// engine.cpp — the p3hip C ABI (include/p3hip.h): weight loading / repacking, pinned
+// staging, slot compaction, launch sequence.  Compiled with hipcc into libp3hip.so.
+//
+// Replaces TrtEngineImpl (cc/nn/engine/trt_engine.cc:85-351) behind nn::Engine
+// (cc/nn/engine/engine.h:22-43).  Differences by design:
+//   * the GoFeatures POD itself (1,860 B) is what crosses PCIe; planes are expanded on
+//     the device (go_features.cc:10-61 restated in k_init) instead of 21,692 B of fp32;
+//   * only slots loaded since the previous run are uploaded and evaluated, compacted
+//     into a dense batch (the TRT engine always runs the full static batch);
+//   * only the consumed outputs (7,556 B / position) come back every run; ownership and
+//     raw logits stay on the device until asked for.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/p3hip.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr float kBnEps = 1e-3f;  // model.py:231
+constexpr int kNLoc = 361;
+constexpr size_t kFeatBytes = sizeof(p3hip_features);
+static_assert(sizeof(p3hip_features) == 1860, "p3hip_features layout");
+static_assert(sizeof(p3hip_result) == 4 * 1892, "p3hip_result layout");
+
+thread_local std::string g_create_error;
+
+struct Tensor {
+  std::vector<int> dims;
+  const float* data;
+  size_t size() const {
+    size_t n = 1;
+    for (int d : dims) n *= d;
+    return n;
+  }
+};
+
+struct WeightFile {
+  int version = 0, nblocks = 0, C = 0, Cb = 0, H = 0, V = 0, bint = 0, inner = 0, btype = 0;
+  std::vector<float> data;
+  std::map<std::string, Tensor> tensors;
+
+  bool load(const char* path, std::string& err) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { err = std::string("cannot open ") + path; return false; }
+    char magic[4];
+    int hdr[10];
+    if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "P3W1", 4) != 0 || fread(hdr, 4, 10, f) != 10) {
+      err = "not a .p3w file"; fclose(f); return false;
+    }
+    version = hdr[0]; nblocks = hdr[1]; C = hdr[2]; Cb = hdr[3]; H = hdr[4]; V = hdr[5];
+    bint = hdr[6]; inner = hdr[7]; btype = hdr[8];
+    int nt = hdr[9];
+    struct Ent { char name[48]; int ndim; int dims[4]; long long off; };
+    std::vector<Ent> ents(nt);
+    long long total = 0;
+    for (auto& e : ents) {
+      if (fread(e.name, 1, 48, f) != 48 || fread(&e.ndim, 4, 1, f) != 1 ||
+          fread(e.dims, 4, 4, f) != 4 || fread(&e.off, 8, 1, f) != 1) {
+        err = "truncated tensor table"; fclose(f); return false;
+      }
+      long long sz = 1;
+      for (int d = 0; d < e.ndim; ++d) sz *= e.dims[d];
+      if (e.off + sz > total) total = e.off + sz;
+    }
+    long pos = ftell(f);
+    pos += (64 - pos % 64) % 64;
+    fseek(f, pos, SEEK_SET);
+    data.resize(total);
+    if (fread(data.data(), 4, total, f) != (size_t)total) { err = "truncated data"; fclose(f); return false; }
+    fclose(f);
+    for (auto& e : ents) {
+      Tensor t;
+      t.dims.assign(e.dims, e.dims + e.ndim);
+      t.data = data.data() + e.off;
+      tensors[std::string(e.name)] = t;
+    }
+    return true;
+  }
+  const Tensor& get(const std::string& n) const {
+    auto it = tensors.find(n);
+    if (it == tensors.end()) { fprintf(stderr, "p3hip: missing tensor %s\n", n.c_str()); abort(); }
+    return it->second;
+  }
+  bool is_broadcast(int i) const { return i % bint == bint - 1; }  // model.py:1002
+};
+
+// ---- device arena -----------------------------------------------------------------
+struct Arena {
+  std::vector<unsigned char> host;
+  size_t add(const void* p, size_t bytes) {
+    size_t off = (host.size() + 255) & ~size_t(255);
+    host.resize(off + bytes);
+    memcpy(host.data() + off, p, bytes);
+    return off;
+  }
+};
+
+// k16 blocks [h(2)][CP couts][8] fp16 in (tap major, channel-pair minor) order; see
+// conv_segment in conv_core.h.  W is HWIO flattened as [taps][cin_total][cout_total].
+void pack_segment(std::vector<_Float16>& dst, const float* W, int taps, int ntaps_pad,
+                  int cin_total, int cout_total, int cin0, int CB, int cout0, int CP) {
+  for (int tap = 0; tap < ntaps_pad; ++tap)
+    for (int q = 0; q < CB / 16; ++q)
+      for (int h = 0; h < 2; ++h)
+        for (int co = 0; co < CP; ++co)
+          for (int e = 0; e < 8; ++e) {
+            int ci = cin0 + q * 16 + h * 8 + e, c = cout0 + co;
+            float v = 0.0f;
+            if (tap < taps && ci < cin_total && c < cout_total)
+              v = W[((size_t)tap * cin_total + ci) * cout_total + c];
+            dst.push_back((_Float16)v);
+          }
+}
+
+struct FoldedBN { size_t scale_off, shift_off; };
+
+struct BlockPlan {
+  int kind;  // 0 btl, 1 nbt, 3 broadcast
+  size_t stream_off = 0;
+  int nms = 0;
+  FoldedBN bn[p3::kMaxBlockLayers];
+  // broadcast extras
+  size_t stream2_off = 0, stream3_off = 0;
+  int nms2 = 0, nms3 = 0;
+  size_t dense_bias_off = 0;
+};
+
+}  // namespace
+
+struct p3hip_engine {
+  std::string path, err;
+  int batch = 0, device = 0;
+  uint32_t flags = 0;
+  WeightFile wf;
+  int n_cu = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  unsigned char* d_arena = nullptr;
+  std::vector<BlockPlan> blocks;
+  size_t init_stream_off = 0; int init_nms = 0;
+  size_t game_w_off = 0, game_b_off = 0;
+  size_t heads_stream_off = 0; int heads_nms = 0;
+  std::map<std::string, size_t> head_off;
+
+  // buffers
+  unsigned char* h_feats = nullptr;       // pinned [batch] slots as loaded
+  unsigned char* h_feats_compact = nullptr;  // pinned, dense
+  unsigned char* d_feats = nullptr;
+  _Float16 *d_x = nullptr, *d_t = nullptr, *d_u = nullptr;
+  float* d_hp = nullptr;
+  float* d_out = nullptr;
+  float* h_out = nullptr;  // pinned [batch][kResultFloats]
+  std::vector<std::atomic<uint8_t>> loaded;
+  std::vector<int> slot_to_row;  // slot -> dense row of the last run (-1 if absent)
+  int last_n = 0;
+
+  bool check(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+  }
+  template <class T>
+  const T* dev(size_t off) const { return reinterpret_cast<const T*>(d_arena + off); }
+};
+
+namespace {
+
+FoldedBN fold_bn(Arena& ar, const WeightFile& wf, const std::string& prefix) {
+  const Tensor& g = wf.get(prefix + ".gamma");
+  const Tensor& b = wf.get(prefix + ".beta");
+  const Tensor& m = wf.get(prefix + ".mean");
+  const Tensor& v = wf.get(prefix + ".var");
+  size_t n = g.size();
+  std::vector<float> sc(n), sh(n);
+  for (size_t i = 0; i < n; ++i) {
+    sc[i] = g.data[i] / std::sqrt(v.data[i] + kBnEps);
+    sh[i] = b.data[i] - m.data[i] * sc[i];
+  }
+  FoldedBN f;
+  f.scale_off = ar.add(sc.data(), n * 4);
+  f.shift_off = ar.add(sh.data(), n * 4);
+  return f;
+}
+
+size_t add_stream(Arena& ar, const std::vector<_Float16>& s, int& nms) {
+  if (s.size() * 2 % 8192 != 0) { fprintf(stderr, "p3hip: stream not macro-step aligned\n"); abort(); }
+  nms = (int)(s.size() * 2 / 8192);
+  return ar.add(s.data(), s.size() * 2);
+}
+
+bool build_plan(p3hip_engine* e, Arena& ar) {
+  const WeightFile& wf = e->wf;
+  const int C = wf.C, Cb = wf.Cb;
+  if (!((C == 256 && Cb == 128) || (C == 128 && Cb == 64)) || wf.H != 32 || wf.V > 128 ||
+      wf.btype > 1 || (wf.btype == 0 && (wf.inner < 1 || wf.inner > 3))) {
+    e->err = "unsupported architecture for the HIP engine (need C in {128,256}, Cb=C/2, H=32, btl/nbt)";
+    return false;
+  }
+  const int CB = Cb;
+  // init conv
+  {
+    std::vector<_Float16> s;
+    const Tensor& w = wf.get("init_conv.w");  // [5][5][15][C]
+    for (int cp = 0; cp < C / 128; ++cp)
+      pack_segment(s, w.data, 25, 26, 15, C, 0, 16, cp * 128, 128);
+    e->init_stream_off = add_stream(ar, s, e->init_nms);
+    e->game_w_off = ar.add(wf.get("init_game.w").data, 8 * C * 4);
+    e->game_b_off = ar.add(wf.get("init_game.b").data, C * 4);
+  }
+  for (int i = 0; i < wf.nblocks; ++i) {
+    BlockPlan bp;
+    const std::string p = "blocks." + std::to_string(i);
+    auto W = [&](int j) { return wf.get(p + ".conv" + std::to_string(j) + ".w").data; };
+    if (wf.is_broadcast(i)) {
+      bp.kind = 3;
+      bp.bn[0] = fold_bn(ar, wf, p + ".bn0");
+      bp.bn[1] = fold_bn(ar, wf, p + ".bn1");
+      const int CPb = (CB == 128) ? 128 : 64;
+      std::vector<_Float16> s0, s1, s2;
+      for (int cp = 0; cp < C / CPb; ++cp)
+        for (int ip = 0; ip < C / CB; ++ip) {
+          pack_segment(s0, W(0), 1, 1, C, C, ip * CB, CB, cp * CPb, CPb);
+          pack_segment(s2, W(1), 1, 1, C, C, ip * CB, CB, cp * CPb, CPb);
+        }
+      const Tensor& dw = wf.get(p + ".dense.w");  // [361 i][361 j]
+      for (int jp = 0; jp < 3; ++jp)
+        for (int q = 0; q < 24; ++q)
+          for (int h = 0; h < 2; ++h)
+            for (int jj = 0; jj < 128; ++jj)
+              for (int el = 0; el < 8; ++el) {
+                int ii = q * 16 + h * 8 + el, j = jp * 128 + jj;
+                float v = (ii < kNLoc && j < kNLoc) ? dw.data[(size_t)ii * kNLoc + j] : 0.0f;
+                s1.push_back((_Float16)v);
+              }
+      bp.stream_off = add_stream(ar, s0, bp.nms);
+      bp.stream2_off = add_stream(ar, s1, bp.nms2);
+      bp.stream3_off = add_stream(ar, s2, bp.nms3);
+      bp.dense_bias_off = ar.add(wf.get(p + ".dense.b").data, kNLoc * 4);
+    } else {
+      bp.kind = wf.btype;
+      const int nconv = (wf.btype == 0) ? wf.inner + 2 : 6;
+      for (int j = 0; j < nconv; ++j) bp.bn[j] = fold_bn(ar, wf, p + ".bn" + std::to_string(j));
+      std::vector<_Float16> s;
+      for (int ip = 0; ip < C / CB; ++ip) pack_segment(s, W(0), 1, 1, C, Cb, ip * CB, CB, 0, CB);
+      for (int j = 1; j < nconv - 1; ++j) pack_segment(s, W(j), 9, 9, Cb, Cb, 0, CB, 0, CB);
+      for (int cp = 0; cp < C / CB; ++cp) pack_segment(s, W(nconv - 1), 1, 1, Cb, C, 0, CB, cp * CB, CB);
+      bp.stream_off = add_stream(ar, s, bp.nms);
+    }
+    e->blocks.push_back(bp);
+  }
+  // heads: conv_p | conv_g | value.conv  -> [C][96]
+  {
+    std::vector<float> w((size_t)C * 96);
+    const float* wp = wf.get("policy.conv_p.w").data;
+    const float* wg = wf.get("policy.conv_g.w").data;
+    const float* wv = wf.get("value.conv.w").data;
+    for (int c = 0; c < C; ++c)
+      for (int o = 0; o < 32; ++o) {
+        w[(size_t)c * 96 + o] = wp[c * 32 + o];
+        w[(size_t)c * 96 + 32 + o] = wg[c * 32 + o];
+        w[(size_t)c * 96 + 64 + o] = wv[c * 32 + o];
+      }
+    std::vector<_Float16> s;
+    for (int cp = 0; cp < 2; ++cp)
+      for (int ip = 0; ip < C / CB; ++ip) pack_segment(s, w.data(), 1, 1, C, 96, ip * CB, CB, cp * 64, 64);
+    e->heads_stream_off = add_stream(ar, s, e->heads_nms);
+    FoldedBN g = fold_bn(ar, wf, "policy.gpool_bn");
+    e->head_off["gbn_scale"] = g.scale_off;
+    e->head_off["gbn_shift"] = g.shift_off;
+    const char* names[] = {"policy.gpool_dense.w", "policy.gpool_dense.b", "policy.out_moves.w",
+                           "policy.out_pass.w", "policy.out_pass.b", "policy.opt_moves.w",
+                           "policy.opt_pass.w", "policy.opt_pass.b", "value.oq_embed.w",
+                           "value.oq_embed.b", "value.oq_out.w", "value.oq_out.b", "value.own.w",
+                           "value.gamma_pre.w", "value.gamma_pre.b", "value.gamma_out.w",
+                           "value.gamma_out.b", "value.score_pre.w", "value.score_pre.b",
+                           "value.score_out.w", "value.score_out.b"};
+    for (const char* n : names) {
+      const Tensor& t = wf.get(n);
+      e->head_off[n] = ar.add(t.data, t.size() * 4);
+    }
+  }
+  return true;
+}
+
+int grid_for(const p3hip_engine* e, int npos, int npos_per_wg) {
+  int wgs = (npos + npos_per_wg - 1) / npos_per_wg;
+  return wgs < e->n_cu ? wgs : e->n_cu;
+}
+
+p3::BlockArgs block_args(p3hip_engine* e, const BlockPlan& bp, int npos) {
+  p3::BlockArgs a{};
+  a.x = e->d_x;
+  a.npos = npos;
+  a.wstream = e->d_arena + bp.stream_off;
+  a.nms_total = bp.nms;
+  for (int j = 0; j < p3::kMaxBlockLayers; ++j) {
+    a.scale[j] = e->dev<float>(bp.bn[j].scale_off);
+    a.shift[j] = e->dev<float>(bp.bn[j].shift_off);
+  }
+  return a;
+}
+
+// Enqueues the whole forward pass for `npos` dense positions already in d_feats.
+bool enqueue_forward(p3hip_engine* e, int npos) {
+  const WeightFile& wf = e->wf;
+  const int C = wf.C;
+  const int npw = (C == 256) ? 1 : 2;
+  hipStream_t s = e->stream;
+  {
+    p3::InitArgs a{};
+    a.feats = e->d_feats; a.x = e->d_x; a.npos = npos;
+    a.wstream = e->d_arena + e->init_stream_off; a.nms_total = e->init_nms;
+    a.game_w = e->dev<float>(e->game_w_off); a.game_b = e->dev<float>(e->game_b_off);
+    if (!e->check(p3::launch_init(C, a, grid_for(e, npos, 1), s), "launch k_init")) return false;
+  }
+  for (const BlockPlan& bp : e->blocks) {
+    if (bp.kind == 3) {
+      p3::Conv1x1Args c0{};
+      c0.in = e->d_x; c0.out16 = e->d_t; c0.npos = npos;
+      c0.wstream = e->d_arena + bp.stream_off; c0.nms_total = bp.nms;
+      c0.scale = e->dev<float>(bp.bn[0].scale_off); c0.shift = e->dev<float>(bp.bn[0].shift_off);
+      if (!e->check(p3::launch_conv1x1(C, 0, c0, grid_for(e, npos, npw), s), "launch conv_first")) return false;
+      p3::BDenseArgs d{};
+      d.t = e->d_t; d.u = e->d_u; d.npos = npos;
+      d.wstream = e->d_arena + bp.stream2_off; d.nms_total = bp.nms2;
+      d.bias = e->dev<float>(bp.dense_bias_off);
+      d.scale = e->dev<float>(bp.bn[1].scale_off); d.shift = e->dev<float>(bp.bn[1].shift_off);
+      if (!e->check(p3::launch_bdense(C, d, grid_for(e, npos, 1), s), "launch bdense")) return false;
+      p3::Conv1x1Args c1{};
+      c1.in = e->d_u; c1.out16 = e->d_x; c1.npos = npos;
+      c1.wstream = e->d_arena + bp.stream3_off; c1.nms_total = bp.nms3;
+      if (!e->check(p3::launch_conv1x1(C, 1, c1, grid_for(e, npos, npw), s), "launch conv_last")) return false;
+    } else {
+      p3::BlockArgs a = block_args(e, bp, npos);
+      if (!e->check(p3::launch_block(C, bp.kind, wf.inner, a, grid_for(e, npos, npw), s), "launch k_block")) return false;
+    }
+  }
+  {
+    p3::Conv1x1Args c{};
+    c.in = e->d_x; c.out32 = e->d_hp; c.npos = npos;
+    c.wstream = e->d_arena + e->heads_stream_off; c.nms_total = e->heads_nms;
+    if (!e->check(p3::launch_conv1x1(C, 2, c, grid_for(e, npos, npw), s), "launch head convs")) return false;
+    p3::HeadsArgs h{};
+    h.hp = e->d_hp; h.out = e->d_out; h.npos = npos; h.V = wf.V;
+    auto F = [&](const char* n) { return e->dev<float>(e->head_off.at(n)); };
+    h.gbn_scale = F("gbn_scale"); h.gbn_shift = F("gbn_shift");
+    h.gd_w = F("policy.gpool_dense.w"); h.gd_b = F("policy.gpool_dense.b");
+    h.moves_w = F("policy.out_moves.w");
+    h.pass_w = F("policy.out_pass.w"); h.pass_b = F("policy.out_pass.b");
+    h.opt_moves_w = F("policy.opt_moves.w");
+    h.opt_pass_w = F("policy.opt_pass.w"); h.opt_pass_b = F("policy.opt_pass.b");
+    h.oq_embed_w = F("value.oq_embed.w"); h.oq_embed_b = F("value.oq_embed.b");
+    h.oq_out_w = F("value.oq_out.w"); h.oq_out_b = F("value.oq_out.b");
+    h.own_w = F("value.own.w");
+    h.gamma_pre_w = F("value.gamma_pre.w"); h.gamma_pre_b = F("value.gamma_pre.b");
+    h.gamma_out_w = F("value.gamma_out.w"); h.gamma_out_b = F("value.gamma_out.b");
+    h.score_pre_w = F("value.score_pre.w"); h.score_pre_b = F("value.score_pre.b");
+    h.score_out_w = F("value.score_out.w"); h.score_out_b = F("value.score_out.b");
+    if (!e->check(p3::launch_heads(h, npos, s), "launch k_heads")) return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* p3hip_create_error(void) { return g_create_error.c_str(); }
+
+p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version,
+                           int device_ordinal, uint32_t flags) {
+  g_create_error.clear();
+  if (version != 1) { g_create_error = "only model version 1 (15 planes + 8 scalars) is supported"; return nullptr; }
+  if (batch_size < 1 || batch_size > (1 << 16)) { g_create_error = "bad batch size"; return nullptr; }
+  p3hip_engine* e = new p3hip_engine();
+  e->path = weights_path;
+  e->batch = batch_size;
+  e->device = device_ordinal;
+  e->flags = flags;
+  auto fail = [&](const std::string& m) {
+    g_create_error = m;
+    p3hip_destroy(e);
+    return (p3hip_engine*)nullptr;
+  };
+  if (!e->wf.load(weights_path, e->err)) return fail(e->err);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_ordinal)
+    return fail("no HIP device " + std::to_string(device_ordinal) + " (the HIP engine has no CPU fallback)");
+  if (!e->check(hipSetDevice(device_ordinal), "hipSetDevice")) return fail(e->err);
+  hipDeviceProp_t prop;
+  if (!e->check(hipGetDeviceProperties(&prop, device_ordinal), "hipGetDeviceProperties")) return fail(e->err);
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(std::string("device is ") + prop.gcnArchName + ", this engine is built for gfx950 only");
+  e->n_cu = prop.multiProcessorCount;
+  Arena ar;
+  if (!build_plan(e, ar)) return fail(e->err);
+  const int C = e->wf.C;
+  const size_t B = batch_size;
+  bool ok = e->check(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate") &&
+            e->check(hipEventCreate(&e->ev0), "hipEventCreate") &&
+            e->check(hipEventCreate(&e->ev1), "hipEventCreate") &&
+            e->check(hipMalloc((void**)&e->d_arena, ar.host.size()), "hipMalloc arena") &&
+            e->check(hipMemcpy(e->d_arena, ar.host.data(), ar.host.size(), hipMemcpyHostToDevice), "upload weights") &&
+            e->check(hipHostMalloc((void**)&e->h_feats, B * kFeatBytes, hipHostMallocDefault), "hipHostMalloc") &&
+            e->check(hipHostMalloc((void**)&e->h_feats_compact, B * kFeatBytes, hipHostMallocDefault), "hipHostMalloc") &&
+            e->check(hipHostMalloc((void**)&e->h_out, B * p3::kResultFloats * 4, hipHostMallocDefault), "hipHostMalloc") &&
+            e->check(hipMalloc((void**)&e->d_feats, B * kFeatBytes), "hipMalloc feats") &&
+            e->check(hipMalloc((void**)&e->d_x, B * C * kNLoc * 2), "hipMalloc x") &&
+            e->check(hipMalloc((void**)&e->d_t, B * C * kNLoc * 2), "hipMalloc t") &&
+            e->check(hipMalloc((void**)&e->d_u, B * C * kNLoc * 2), "hipMalloc u") &&
+            e->check(hipMalloc((void**)&e->d_hp, B * 96 * kNLoc * 4), "hipMalloc hp") &&
+            e->check(hipMalloc((void**)&e->d_out, B * p3::kOutStride * 4), "hipMalloc out");
+  if (!ok) return fail(e->err);
+  memset(e->h_feats, 0, B * kFeatBytes);
+  hipMemset(e->d_feats, 0, B * kFeatBytes);
+  hipMemset(e->d_out, 0, B * p3::kOutStride * 4);
+  e->loaded = std::vector<std::atomic<uint8_t>>(B);
+  for (auto& a : e->loaded) a.store(0);
+  e->slot_to_row.assign(B, -1);
+  return e;
+}
+
+void p3hip_destroy(p3hip_engine* e) {
+  if (!e) return;
+  if (e->stream) hipStreamSynchronize(e->stream);
+  hipFree(e->d_arena); hipFree(e->d_feats); hipFree(e->d_x); hipFree(e->d_t); hipFree(e->d_u);
+  hipFree(e->d_hp); hipFree(e->d_out);
+  if (e->h_feats) hipHostFree(e->h_feats);
+  if (e->h_feats_compact) hipHostFree(e->h_feats_compact);
+  if (e->h_out) hipHostFree(e->h_out);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  if (e->stream) hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int p3hip_kind(const p3hip_engine*) { return P3HIP_KIND_HIP; }
+const char* p3hip_path(const p3hip_engine* e) { return e->path.c_str(); }
+int p3hip_batch_size(const p3hip_engine* e) { return e->batch; }
+const char* p3hip_last_error(const p3hip_engine* e) { return e->err.c_str(); }
+
+int p3hip_load_slot(p3hip_engine* e, int slot, const p3hip_features* f) {
+  if (slot < 0 || slot >= e->batch) return 1;
+  memcpy(e->h_feats + (size_t)slot * kFeatBytes, f, kFeatBytes);
+  e->loaded[slot].store(1, std::memory_order_release);
+  return 0;
+}
+
+static int gather_loaded(p3hip_engine* e) {
+  int n = 0;
+  const bool all = (e->flags & P3HIP_FLAG_RUN_ALL_SLOTS) != 0;
+  for (int s = 0; s < e->batch; ++s) {
+    bool on = e->loaded[s].exchange(0, std::memory_order_acquire) != 0;
+    if (on || all) {
+      memcpy(e->h_feats_compact + (size_t)n * kFeatBytes, e->h_feats + (size_t)s * kFeatBytes, kFeatBytes);
+      e->slot_to_row[s] = n++;
+    } else {
+      e->slot_to_row[s] = -1;
+    }
+  }
+  e->last_n = n;
+  return n;
+}
+
+int p3hip_upload(p3hip_engine* e) {
+  int n = gather_loaded(e);
+  if (n == 0) return 0;
+  if (!e->check(hipMemcpyAsync(e->d_feats, e->h_feats_compact, (size_t)n * kFeatBytes,
+                               hipMemcpyHostToDevice, e->stream), "H2D features")) return 1;
+  return e->check(hipStreamSynchronize(e->stream), "sync") ? 0 : 1;
+}
+
+int p3hip_forward_resident(p3hip_engine* e, int n_positions) {
+  if (n_positions < 1 || n_positions > e->batch) return 1;
+  return enqueue_forward(e, n_positions) ? 0 : 1;
+}
+
+int p3hip_sync(p3hip_engine* e) { return e->check(hipStreamSynchronize(e->stream), "sync") ? 0 : 1; }
+
+int p3hip_run(p3hip_engine* e) {
+  int n = gather_loaded(e);
+  if (n == 0) return 0;
+  if (!e->check(hipMemcpyAsync(e->d_feats, e->h_feats_compact, (size_t)n * kFeatBytes,
+                               hipMemcpyHostToDevice, e->stream), "H2D features")) return 1;
+  if (!enqueue_forward(e, n)) return 1;
+  if (!e->check(hipMemcpy2DAsync(e->h_out, p3::kResultFloats * 4, e->d_out, p3::kOutStride * 4,
+                                 p3::kResultFloats * 4, n, hipMemcpyDeviceToHost, e->stream), "D2H results")) return 1;
+  return e->check(hipStreamSynchronize(e->stream), "sync") ? 0 : 1;
+}
+
+int p3hip_get_slot(p3hip_engine* e, int slot, p3hip_result* out) {
+  if (slot < 0 || slot >= e->batch) return 1;
+  int row = e->slot_to_row[slot];
+  if (row < 0) return 2;
+  const float* r = e->h_out + (size_t)row * p3::kResultFloats;
+  memcpy(out->move_logits, r + p3::kOffMoveLogits, 362 * 4);
+  memcpy(out->move_probs, r + p3::kOffMoveProbs, 362 * 4);
+  memcpy(out->value_probs, r + p3::kOffValueProbs, 2 * 4);
+  memcpy(out->score_probs, r + p3::kOffScoreProbs, 800 * 4);
+  memcpy(out->opt_move_probs, r + p3::kOffOptProbs, 362 * 4);
+  out->err2_outcome = r[p3::kOffErr2];
+  return 0;
+}
+
+int p3hip_get_ownership(p3hip_engine* e, int slot, float out[P3HIP_NUM_LOCS]) {
+  if (slot < 0 || slot >= e->batch) return 1;
+  int row = e->slot_to_row[slot];
+  if (row < 0) return 2;
+  return e->check(hipMemcpy(out, e->d_out + (size_t)row * p3::kOutStride + p3::kOffOwnership,
+                            kNLoc * 4, hipMemcpyDeviceToHost), "D2H ownership") ? 0 : 1;
+}
+
+int p3hip_get_raw(p3hip_engine* e, int slot, float* out) {
+  if (slot < 0 || slot >= e->batch) return 1;
+  int row = e->slot_to_row[slot];
+  if (row < 0) return 2;
+  std::vector<float> rec(p3::kOutStride);
+  if (!e->check(hipMemcpy(rec.data(), e->d_out + (size_t)row * p3::kOutStride, p3::kOutStride * 4,
+                          hipMemcpyDeviceToHost), "D2H raw")) return 1;
+  memcpy(out, rec.data() + p3::kOffMoveLogits, 362 * 4);
+  memcpy(out + 362, rec.data() + p3::kOffOptLogits, 362 * 4);
+  memcpy(out + 724, rec.data() + p3::kOffOutcomeLogits, 2 * 4);
+  memcpy(out + 726, rec.data() + p3::kOffScoreLogits, 800 * 4);
+  memcpy(out + 1526, rec.data() + p3::kOffOwnership, 361 * 4);
+  out[1887] = rec[p3::kOffErr2];
+  out[1888] = rec[p3::kOffGamma];
+  return 0;
+}
+
+void p3hip_flops_per_position(const p3hip_engine* e, double* total, double* conv3x3) {
+  const WeightFile& w = e->wf;
+  const double C = w.C, Cb = w.Cb, H = w.H, V = w.V, L = kNLoc;
+  double mac = L * 25 * 15 * C + 8 * C, mac3 = 0;
+  for (int i = 0; i < w.nblocks; ++i) {
+    if (w.is_broadcast(i)) mac += L * 2 * C * C + C * L * L;
+    else if (w.btype == 0) { mac += L * 2 * C * Cb; mac3 += L * w.inner * 9 * Cb * Cb; }
+    else if (w.btype == 1) { mac += L * 2 * C * Cb; mac3 += L * 4 * 9 * Cb * Cb; }
+  }
+  mac += L * 3 * C * H + L * H * 5 + 2 * H * H + 2 * H * 4 + 2 * H * V * 2 + V * (14 + 51 + 1) +
+         (2 * H + 1) * V + 800 * V;
+  if (total) *total = 2.0 * (mac + mac3);
+  if (conv3x3) *conv3x3 = 2.0 * mac3;
+}
+
+double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
+                               double* flops_per_launch, const char** kernel_name) {
+  const WeightFile& wf = e->wf;
+  const BlockPlan* bp = nullptr;
+  for (const BlockPlan& b : e->blocks)
+    if (b.kind != 3) { bp = &b; break; }
+  if (!bp || n_positions < 1 || n_positions > e->batch || iters < 1) return -1.0;
+  const int C = wf.C, npw = (C == 256) ? 1 : 2;
+  p3::BlockArgs a = block_args(e, *bp, n_positions);
+  const int grid = grid_for(e, n_positions, npw);
+  // x is updated in place by the block kernel: keep a pristine copy in the scratch buffer
+  // and restore it (untimed) before every timed launch so the data stays in range.
+  const size_t xbytes = (size_t)n_positions * C * kNLoc * 2;
+  if (!e->check(hipMemcpyAsync(e->d_t, e->d_x, xbytes, hipMemcpyDeviceToDevice, e->stream), "save x")) return -1.0;
+  if (!e->check(p3::launch_block(C, bp->kind, wf.inner, a, grid, e->stream), "warm-up launch")) return -1.0;
+  double total_ms = 0.0;
+  for (int i = 0; i < iters; ++i) {
+    hipMemcpyAsync(e->d_x, e->d_t, xbytes, hipMemcpyDeviceToDevice, e->stream);
+    hipEventRecord(e->ev0, e->stream);
+    if (!e->check(p3::launch_block(C, bp->kind, wf.inner, a, grid, e->stream), "timed launch")) return -1.0;
+    hipEventRecord(e->ev1, e->stream);
+    if (!e->check(hipEventSynchronize(e->ev1), "event sync")) return -1.0;
+    float ms = 0;
+    hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    total_ms += ms;
+  }
+  hipMemcpyAsync(e->d_x, e->d_t, xbytes, hipMemcpyDeviceToDevice, e->stream);
+  hipStreamSynchronize(e->stream);
+  const float ms = (float)total_ms;
+  const double n3 = (wf.btype == 0) ? wf.inner : 4;
+  if (flops_per_launch) *flops_per_launch = 2.0 * n_positions * kNLoc * n3 * 9.0 * wf.Cb * wf.Cb;
+  if (kernel_name) *kernel_name = p3::block_kernel_name(C, bp->kind, wf.inner);
+  return ms / iters;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// kernels.h — argument structs and launchers shared by kernels.hip and engine.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace p3 {
+
+// Per-position fp32 output record written by k_heads.
+//   [result region, copied to the host every run: 7,556 B]
+constexpr int kOffMoveLogits = 0;      // 362  -> NNInferResult::move_logits
+constexpr int kOffMoveProbs = 362;     // 362  -> move_probs
+constexpr int kOffValueProbs = 724;    // 2    -> value_probs
+constexpr int kOffScoreProbs = 726;    // 800  -> score_probs
+constexpr int kOffOptProbs = 1526;     // 362  -> opt_move_probs
+constexpr int kOffErr2 = 1888;         // 1    -> err2_outcome
+constexpr int kResultFloats = 1889;
+//   [debug / optional region, copied on demand]
+constexpr int kOffOptLogits = 1889;      // 362
+constexpr int kOffOutcomeLogits = 2251;  // 2
+constexpr int kOffScoreLogits = 2253;    // 800
+constexpr int kOffOwnership = 3053;      // 361
+constexpr int kOffGamma = 3414;          // 1
+constexpr int kOutStride = 3416;
+
+constexpr int kMaxBlockLayers = 8;
+
+struct BlockArgs {
+  _Float16* x;          // residual stream, updated in place
+  int npos;
+  const void* wstream;  // packed weight stream of this block
+  int nms_total;        // its length in 8 KiB macro-steps
+  const float* scale[kMaxBlockLayers];  // folded BN of conv j's prologue
+  const float* shift[kMaxBlockLayers];
+};
+
+struct InitArgs {
+  const void* feats;  // npos x p3hip_features (1860 B each)
+  _Float16* x;
+  int npos;
+  const void* wstream;
+  int nms_total;
+  const float* game_w;  // [8][C]
+  const float* game_b;  // [C]
+};
+
+struct Conv1x1Args {
+  const _Float16* in;
+  _Float16* out16;
+  float* out32;
+  int npos;
+  const void* wstream;
+  int nms_total;
+  const float* scale;
+  const float* shift;
+};
+
+struct BDenseArgs {
+  const _Float16* t;
+  _Float16* u;
+  int npos;
+  const void* wstream;
+  int nms_total;
+  const float* bias;   // dense bias [361]
+  const float* scale;  // folded bn1 [C]
+  const float* shift;
+};
+
+struct HeadsArgs {
+  const float* hp;  // [npos][96][361]
+  float* out;       // [npos][kOutStride]
+  int npos;
+  int V;
+  const float *gbn_scale, *gbn_shift;      // policy.gpool_bn folded [32]
+  const float *gd_w, *gd_b;                // policy.gpool_dense [64][32], [32]
+  const float *moves_w;                    // policy.out_moves [32][2]
+  const float *pass_w, *pass_b;            // policy.out_pass [64][2], [2]
+  const float *opt_moves_w;                // [32]
+  const float *opt_pass_w, *opt_pass_b;    // [64], [1]
+  const float *oq_embed_w, *oq_embed_b;    // [64][V], [V]
+  const float *oq_out_w, *oq_out_b;        // [V][14], [14]
+  const float *own_w;                      // [32]
+  const float *gamma_pre_w, *gamma_pre_b;  // [64][V], [V]
+  const float *gamma_out_w, *gamma_out_b;  // [V], [1]
+  const float *score_pre_w, *score_pre_b;  // [65][V], [V]
+  const float *score_out_w, *score_out_b;  // [V], [1]
+};
+
+hipError_t launch_block(int C, int kind, int L, const BlockArgs& a, int grid, hipStream_t s);
+hipError_t launch_init(int C, const InitArgs& a, int grid, hipStream_t s);
+// which: 0 = broadcast conv_first (bn+mish prologue, mish epilogue), 1 = broadcast
+// conv_last (+residual), 2 = head convs (fp32 out, COUT = 96)
+hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipStream_t s);
+hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s);
+hipError_t launch_heads(const HeadsArgs& a, int grid, hipStream_t s);
+const char* block_kernel_name(int C, int kind, int L);
+
+}  // namespace p3

@@ -1,0 +1,620 @@
+// kernels.hip — gfx950 kernels of the policy/value net forward pass.
+//
+// Arithmetic spec: reference python/model.py (cited per kernel).  Layouts:
+//   residual stream / activations in HBM : x[pos][C/8][361][8]  fp16 (channel-blocked)
+//   head pre-activations                  : hp[pos][96][361]     fp32
+//   outputs                               : out[pos][kOutStride] fp32 (see kernels.h)
+// All trunk convs run through conv_core.h (LDS-resident activations, MFMA implicit GEMM,
+// glds weight ring).  One workgroup = 512 threads; grid-stride loop over positions.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include "conv_core.h"
+
+namespace p3 {
+
+// =======================================================================================
+// Fused residual blocks.  KIND 0 = bottleneck (btl), 1 = nested bottleneck (nbt).
+//   btl: BottleneckResidualConvBlock, model.py:372-425 —
+//        x + conv1x1_{L+1}( ... conv3x3_j( ... conv1x1_0(x)))   each conv = conv(mish(bn(.)))
+//   nbt: NbtResidualBlock, model.py:430-486 —
+//        t = conv1x1_0(x); t += conv3(conv3(t)); t += conv3(conv3(t)); x + conv1x1_5(t)
+// Weight stream order (must match pack_block_stream in engine.cpp):
+//   reduce: for each CB-slice of C input channels; inner 3x3 convs in order; expand: for
+//   each CB-slice of C output channels.
+// =======================================================================================
+template <int C, int CB, int KIND, int L>
+__global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
+  constexpr int NPOS = 128 / CB;
+  using G = Geo<NPOS, CB, 3>;
+  using T = Tiling<G, CB>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr uint32_t kRingOff = G::ACT_BYTES;
+
+  act_zero<G>(smem);
+  Ring ring;
+  ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
+  lds_barrier();
+
+  for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS) {
+    f32x16 acc[2][T::NT];
+    // ---- reduce 1x1 (C -> CB), prologue bn0+mish applied while staging --------------
+    acc_zero<G, CB>(acc);
+#pragma unroll 1
+    for (int ip = 0; ip < C / CB; ++ip) {
+      if (ip > 0) lds_barrier();
+      stage_in<G, true>(smem, a.x, C, pos0, a.npos, ip * G::NCH, a.scale[0], a.shift[0]);
+      conv_segment<G, CB, 1, 1>(ring, smem, acc);
+    }
+    if (KIND == 0) {
+#pragma unroll 1
+      for (int j = 1; j <= L; ++j) {
+        lds_barrier();
+        epilogue_to_act<G, CB>(smem, acc, a.scale[j], a.shift[j], 0);
+        acc_zero<G, CB>(acc);
+        conv_segment<G, CB, 3, 9>(ring, smem, acc);
+      }
+      lds_barrier();
+      epilogue_to_act<G, CB>(smem, acc, a.scale[L + 1], a.shift[L + 1], 0);
+    } else {
+      // nbt: keep the raw inner residual t in registers (fp32, same tile as acc)
+      f32x16 t[2][T::NT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < T::NT; ++j) t[mt][j] = acc[mt][j];
+#pragma unroll 1
+      for (int r = 0; r < 2; ++r) {
+        lds_barrier();
+        epilogue_to_act<G, CB>(smem, t, a.scale[1 + 2 * r], a.shift[1 + 2 * r], 0);
+        acc_zero<G, CB>(acc);
+        conv_segment<G, CB, 3, 9>(ring, smem, acc);
+        lds_barrier();
+        epilogue_to_act<G, CB>(smem, acc, a.scale[2 + 2 * r], a.shift[2 + 2 * r], 0);
+        acc_zero<G, CB>(acc);
+        conv_segment<G, CB, 3, 9>(ring, smem, acc);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int j = 0; j < T::NT; ++j) t[mt][j] += acc[mt][j];
+      }
+      lds_barrier();
+      epilogue_to_act<G, CB>(smem, t, a.scale[5], a.shift[5], 0);
+    }
+    // ---- expand 1x1 (CB -> C) + residual, straight to HBM ---------------------------
+#pragma unroll 1
+    for (int cp = 0; cp < C / CB; ++cp) {
+      acc_zero<G, CB>(acc);
+      conv_segment<G, CB, 1, 1>(ring, smem, acc);
+      epilogue_to_global<G, CB, true>(acc, a.x, C, pos0, a.npos, cp * CB);
+    }
+    lds_barrier();
+  }
+  ring_drain();
+}
+
+// =======================================================================================
+// Initial 5x5 conv over the 15 binary input planes + game-state dense, model.py:1230-1237.
+// Input planes are expanded on the fly from the packed GoFeatures bytes (restating
+// LoadPlanes/LoadFeatures, cc/nn/engine/go_features.cc:10-61): nothing but the 1.9 KB POD
+// crosses PCIe.  Channel 15 is a zero pad.
+// =======================================================================================
+struct FeatOff {  // byte offsets inside p3hip_features (include/p3hip.h)
+  static constexpr int color = 4, komi = 8, board = 12, last = 376, atari = 416, two = 777,
+                       three = 1138, ladder = 1499, size = 1860;
+};
+
+template <int C>
+__global__ void __launch_bounds__(kWG, 2) k_init(InitArgs a) {
+  using G = Geo<1, 16, 5>;
+  constexpr int CP = 128;
+  using T = Tiling<G, CP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr uint32_t kRingOff = G::ACT_BYTES;
+  act_zero<G>(smem);
+  Ring ring;
+  ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
+  lds_barrier();
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lg = wid / T::CG;
+  const int lr = lane & 31, h = lane >> 5;
+
+  for (int pos = blockIdx.x; pos < a.npos; pos += gridDim.x) {
+    const unsigned char* f = (const unsigned char*)a.feats + (size_t)pos * FeatOff::size;
+    const int color = (signed char)f[FeatOff::color];
+    // ---- planes -> LDS (one thread per board point) ---------------------------------
+    for (int loc = threadIdx.x; loc < kNLoc; loc += kWG) {
+      h8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = {0, 0, 0, 0, 0, 0, 0, 0};
+      auto our = [&](int off) {
+        return (_Float16)((signed char)f[off + loc] == color ? 1.0f : 0.0f);
+      };
+      auto opp = [&](int off) {
+        return (_Float16)((signed char)f[off + loc] == -color ? 1.0f : 0.0f);
+      };
+      lo[0] = our(FeatOff::board); lo[1] = opp(FeatOff::board);
+      lo[7] = our(FeatOff::atari); hi[0] = opp(FeatOff::atari);
+      hi[1] = our(FeatOff::two); hi[2] = opp(FeatOff::two);
+      hi[3] = our(FeatOff::three); hi[4] = opp(FeatOff::three);
+      hi[5] = our(FeatOff::ladder); hi[6] = opp(FeatOff::ladder);
+      const int y = (loc * 3450) >> 16, xx = loc - y * kBL;
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const int* lm = (const int*)(f + FeatOff::last + m * 8);
+        if (lm[0] == y && lm[1] == xx) lo[2 + m] = (_Float16)1.0f;  // pass {19,0}/noop never match
+      }
+      const int s = G::PADTOP + y * G::S + xx;
+      const int sw = swz<G::NCH>(s);
+      *(h8*)(smem + s * G::SLOTB + (0 ^ sw) * 16) = lo;
+      *(h8*)(smem + s * G::SLOTB + (1 ^ sw) * 16) = hi;
+    }
+    // ---- game-state scalars (LoadFeatures) ------------------------------------------
+    float gsv[8];
+    gsv[0] = color == 1 ? 1.0f : 0.0f;
+    gsv[1] = color == 1 ? 0.0f : 1.0f;
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      const int* lm = (const int*)(f + FeatOff::last + m * 8);
+      gsv[2 + m] = (lm[0] == 19 && lm[1] == 0) ? 1.0f : 0.0f;
+    }
+    gsv[7] = (color == 1 ? -1.0f : 1.0f) * (*(const float*)(f + FeatOff::komi)) / 15.0f;
+
+#pragma unroll 1
+    for (int cp = 0; cp < C / CP; ++cp) {
+      f32x16 acc[2][T::NT];
+      acc_zero<G, CP>(acc);
+      conv_segment<G, CP, 5, 26>(ring, smem, acc);
+      // epilogue: + (gs . Wg + b)[c]  -> x
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int c = cp * CP + acc_chan<G, CP>(mt, g4);
+          f32x4 bias = *(const f32x4*)(a.game_b + c);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const f32x4 w = *(const f32x4*)(a.game_w + k * C + c);
+            bias += w * gsv[k];
+          }
+#pragma unroll
+          for (int j = 0; j < T::NT; ++j) {
+            const int t = lg + j * T::LG;
+            if (t >= G::NT_TOTAL) continue;
+            const int r = t * 32 + lr;
+            int loc;
+            if (!row_valid<G::S>(r, loc)) continue;
+            h4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (_Float16)(acc[mt][j][g4 * 4 + i] + bias[i]);
+            *(h4*)(a.x + ((size_t)pos * (C / 8) + (c >> 3)) * (kNLoc * 8) + loc * 8 + h * 4) = o;
+          }
+        }
+    }
+    lds_barrier();
+    // clear the 5 last-move/stone planes for the next position: every valid slot is
+    // rewritten in full by the staging loop above, so nothing to do.
+  }
+  ring_drain();
+}
+
+// =======================================================================================
+// Generic 1x1 conv kernel over the channel-blocked stream.
+//   PRE  : apply mish(bn(.)) while staging (ConvPreActivation prologue)
+//   EPI 0: out = mish(acc)               -> y (fp16)   [broadcast conv_first + BroadcastPreAct act,
+//                                                       model.py:556-560,590-596]
+//   EPI 1: x  += acc                      (residual)   [broadcast conv_last, model.py:600-606]
+//   EPI 2: hp  = acc (fp32 [pos][COUT][361])            [policy conv_p/conv_g, value conv;
+//                                                       model.py:783-786,889]
+// =======================================================================================
+template <int CIN, int COUT, bool PRE, int EPI>
+__global__ void __launch_bounds__(kWG, 2) k_conv1x1(Conv1x1Args a) {
+  constexpr int CB = CIN >= 256 ? 128 : 64;
+  constexpr int NPOS = 128 / CB;
+  constexpr int CP = (COUT >= 128 && CB == 128) ? 128 : 64;  // cout pass
+  using G = Geo<NPOS, CB, 1>;
+  using T = Tiling<G, CP>;
+  constexpr int NCP = (COUT + CP - 1) / CP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr uint32_t kRingOff = G::ACT_BYTES;
+  act_zero<G>(smem);
+  Ring ring;
+  ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
+  lds_barrier();
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lg = wid / T::CG;
+  const int lr = lane & 31;
+
+  for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS) {
+#pragma unroll 1
+    for (int cp = 0; cp < NCP; ++cp) {
+      f32x16 acc[2][T::NT];
+      acc_zero<G, CP>(acc);
+#pragma unroll 1
+      for (int ip = 0; ip < CIN / CB; ++ip) {
+        lds_barrier();
+        stage_in<G, PRE>(smem, a.in, CIN, pos0, a.npos, ip * G::NCH, a.scale, a.shift);
+        conv_segment<G, CP, 1, 1>(ring, smem, acc);
+      }
+      if (EPI == 1) {
+        epilogue_to_global<G, CP, true>(acc, a.out16, COUT, pos0, a.npos, cp * CP);
+      } else if (EPI == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int j = 0; j < T::NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][j][i] = mish_f(acc[mt][j][i]);
+        epilogue_to_global<G, CP, false>(acc, a.out16, COUT, pos0, a.npos, cp * CP);
+      } else {
+        const int h = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < T::NT; ++j) {
+          const int t = lg + j * T::LG;
+          if (t >= G::NT_TOTAL) continue;
+          const int p = t / G::NT_POS, tt = t - p * G::NT_POS;
+          const int loc = tt * 32 + lr;  // S == 19: row == loc
+          if (loc >= kNLoc || pos0 + p >= a.npos) continue;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int wid_cg = wid % T::CG;
+              const int c = cp * CP + wid_cg * 64 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+              if (c < COUT) a.out32[((size_t)(pos0 + p) * COUT + c) * kNLoc + loc] = acc[mt][j][i];
+            }
+        }
+      }
+    }
+  }
+  lds_barrier();
+  ring_drain();
+}
+
+// =======================================================================================
+// Broadcast dense: per channel c, u[c][j] = sum_i t[c][i] W[i][j] + b[j]  (Dense(361) over
+// the flattened board, weights shared by all channels; BroadcastPreAct.call, model.py:
+// 556-567; `t` already carries the mish).  Then the following ConvPreActivation prologue
+// mish(bn1(u)) is applied here so that conv_last runs with PRE = false.
+//   MFMA orientation: D[c][j] = sum_i Tt[c][i] * Wt[j][i]  (A = activations transposed in
+//   LDS to [c][i], B = dense matrix rows streamed through the ring).
+// =======================================================================================
+constexpr int kTtStride = 784;  // bytes per channel row in LDS: 384 fp16 + 16 B pad
+
+template <int C>
+__global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CH = 128;                       // channels resident per pass
+  constexpr uint32_t kTtBytes = CH * kTtStride;  // 100,352
+  constexpr uint32_t kRingOff = kTtBytes;
+  constexpr int NQ = 24;                        // k16 steps over i (384)
+  for (int i = threadIdx.x * 16; i < (int)kTtBytes; i += kWG * 16) *(f32x4*)(smem + i) = f32x4{0, 0, 0, 0};
+  Ring ring;
+  ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
+  lds_barrier();
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int jg = wid & 1;        // which 64 of the 128 j rows in this pass
+  const int ct = wid >> 1;       // channel tile (32 channels) 0..3
+  const int lr = lane & 31, h = lane >> 5;
+
+  for (int pos = blockIdx.x; pos < a.npos; pos += gridDim.x) {
+#pragma unroll 1
+    for (int half = 0; half < C / CH; ++half) {
+      lds_barrier();
+      // ---- transpose-stage t[pos][cblk][loc][8] -> Tt[c][i] --------------------------
+      for (int it = threadIdx.x; it < (CH / 8) * kNLoc; it += kWG) {
+        const int kb = it / kNLoc, loc = it - kb * kNLoc;
+        const h8 v = *(const h8*)(a.t + ((size_t)pos * (C / 8) + half * (CH / 8) + kb) * (kNLoc * 8) + loc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *(_Float16*)(smem + (kb * 8 + e) * kTtStride + loc * 2) = v[e];
+      }
+#pragma unroll 1
+      for (int jp = 0; jp < 3; ++jp) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
+        const uint32_t b_off = (uint32_t)((h * 128 + jg * 64 + lr) * 16);
+        const uint32_t a_base = (uint32_t)((ct * 32 + lr) * kTtStride + h * 16);
+        uint32_t wslot = 0;
+#pragma unroll 2
+        for (int q = 0; q < NQ; ++q) {
+          if ((q & 1) == 0) wslot = ring_acquire(ring, smem);
+          const uint32_t wk = wslot + (q & 1) * 4096;
+          const h8 av = *(const h8*)(smem + a_base + q * 32);
+          const h8 b0 = *(const h8*)(smem + wk + b_off);
+          const h8 b1 = *(const h8*)(smem + wk + b_off + 512);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
+        }
+        // epilogue: rows = channel (regs), cols = j (lanes)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int j = jp * 128 + jg * 64 + mt * 32 + lr;
+          if (j >= kNLoc) continue;
+          const float bj = a.bias[j];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int c = half * CH + ct * 32 + g4 * 8 + h * 4;
+            const f32x4 sc = *(const f32x4*)(a.scale + c);
+            const f32x4 sh = *(const f32x4*)(a.shift + c);
+            h4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (_Float16)mish_f((acc[mt][g4 * 4 + i] + bj) * sc[i] + sh[i]);
+            *(h4*)(a.u + ((size_t)pos * (C / 8) + (c >> 3)) * (kNLoc * 8) + j * 8 + h * 4) = o;
+          }
+        }
+      }
+    }
+  }
+  lds_barrier();
+  ring_drain();
+}
+
+// =======================================================================================
+// Heads tail: everything after the three 1x1 head convs (hp = [p(32) | g(32) | v(32)]).
+// PolicyHead.call model.py:783-812, GlobalPoolBias.call :696-706, ValueHead.call :887-979,
+// output softmaxes :1265-1267; optimistic-policy softmax is the reference's host-side
+// core::Softmax in TrtEngineImpl::GetBatch (cc/nn/engine/trt_engine.cc:347-348) moved on
+// device.  fp32 VALU throughout; one 256-thread workgroup per position.
+// =======================================================================================
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// block-wide (256 threads) reductions through LDS scratch `red` (>= 8 floats)
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+  return r;
+}
+
+__device__ void softmax_block(const float* in, float* out, int n, float* red) {
+  float m = -3.0e38f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, in[i]);
+  m = block_reduce(m, red, true);
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float e = __expf(in[i] - m);
+    out[i] = e;
+    s += e;
+  }
+  s = block_reduce(s, red, false);
+  const float inv = 1.0f / s;
+  for (int i = threadIdx.x; i < n; i += 256) out[i] *= inv;
+}
+
+template <int H>
+__global__ void __launch_bounds__(256) k_heads(HeadsArgs a) {
+  static_assert(H == 32, "head channels");
+  __shared__ float gp[2 * H], vp[2 * H], gbias[H], emb[128], gpre[128], base[128], red[8];
+  __shared__ float s_logits[800], s_pi[362], s_opt[362];
+  __shared__ float s_misc[4];
+  const int V = a.V;
+  for (int pos = blockIdx.x; pos < a.npos; pos += gridDim.x) {
+    const float* hp = a.hp + (size_t)pos * 3 * H * kNLoc;
+    float* out = a.out + (size_t)pos * kOutStride;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // ---- pooled g (after bn+mish) and pooled v (raw): one wave per channel ----------
+    for (int c = wid; c < 2 * H; c += 4) {
+      const bool is_g = c < H;
+      const int ch = is_g ? c : c - H;
+      const float* src = hp + (size_t)(is_g ? H + ch : 2 * H + ch) * kNLoc;
+      const float sc = is_g ? a.gbn_scale[ch] : 1.0f, sh = is_g ? a.gbn_shift[ch] : 0.0f;
+      float s = 0.0f, m = -3.0e38f;
+      for (int i = lane; i < kNLoc; i += 64) {
+        float v = src[i];
+        if (is_g) v = mish_f(v * sc + sh);
+        s += v;
+        m = fmaxf(m, v);
+      }
+      s = wave_sum(s);
+      m = wave_max(m);
+      if (lane == 0) {
+        float* dst = is_g ? gp : vp;
+        dst[ch] = s * (1.0f / kNLoc);
+        dst[H + ch] = m;
+      }
+    }
+    __syncthreads();
+    // ---- small dense layers ----------------------------------------------------------
+    if (threadIdx.x < H) {
+      float s = a.gd_b[threadIdx.x];
+      for (int k = 0; k < 2 * H; ++k) s += gp[k] * a.gd_w[k * H + threadIdx.x];
+      gbias[threadIdx.x] = s;
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + V) {
+      const int o = threadIdx.x - 64;
+      float s = a.oq_embed_b[o], g = a.gamma_pre_b[o], b = a.score_pre_b[o];
+      for (int k = 0; k < 2 * H; ++k) {
+        s += vp[k] * a.oq_embed_w[k * V + o];
+        g += vp[k] * a.gamma_pre_w[k * V + o];
+        b += vp[k] * a.score_pre_w[k * V + o];
+      }
+      emb[o] = mish_f(s);
+      gpre[o] = mish_f(g);
+      base[o] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 14) {
+      float s = a.oq_out_b[threadIdx.x];
+      for (int k = 0; k < V; ++k) s += emb[k] * a.oq_out_w[k * 14 + threadIdx.x];
+      if (threadIdx.x == 0) out[kOffOutcomeLogits] = s, s_misc[0] = s;
+      if (threadIdx.x == 1) out[kOffOutcomeLogits + 1] = s, s_misc[1] = s;
+      if (threadIdx.x == 5) out[kOffErr2] = 4.0f / (1.0f + __expf(-s));
+    } else if (threadIdx.x == 64) {
+      float s = a.gamma_out_b[0];
+      for (int k = 0; k < V; ++k) s += gpre[k] * a.gamma_out_w[k];
+      out[kOffGamma] = s;
+      float sp = s > 20.0f ? s : log1pf(__expf(s));
+      s_misc[2] = fminf(sp, 10.0f);
+    } else if (threadIdx.x == 128) {
+      float s2[2] = {a.pass_b[0], a.pass_b[1]};
+      float so = a.opt_pass_b[0];
+      for (int k = 0; k < 2 * H; ++k) {
+        s2[0] += gp[k] * a.pass_w[k * 2];
+        s2[1] += gp[k] * a.pass_w[k * 2 + 1];
+        so += gp[k] * a.opt_pass_w[k];
+      }
+      s_pi[361] = s2[0] - 3.0f;
+      s_opt[361] = so - 3.0f;
+    }
+    __syncthreads();
+    // ---- per-location policy logits and ownership -----------------------------------
+    for (int i = threadIdx.x; i < kNLoc; i += 256) {
+      float pi = 0.0f, po = 0.0f, ow = 0.0f;
+#pragma unroll 8
+      for (int c = 0; c < H; ++c) {
+        const float p = mish_f(hp[(size_t)c * kNLoc + i] + gbias[c]);
+        pi += p * a.moves_w[c * 2];
+        po += p * a.opt_moves_w[c];
+        ow += hp[(size_t)(2 * H + c) * kNLoc + i] * a.own_w[c];
+      }
+      s_pi[i] = pi;
+      s_opt[i] = po;
+      out[kOffOwnership + i] = tanhf(ow);
+    }
+    // ---- score logits: 800 bins x V ---------------------------------------------------
+    for (int sidx = threadIdx.x; sidx < 800; sidx += 256) {
+      const float sc = 0.05f * (float)(sidx - 400) + 0.025f;
+      float s = a.score_out_b[0];
+      for (int k = 0; k < V; ++k) s += mish_f(base[k] + sc * a.score_pre_w[(2 * H) * V + k]) * a.score_out_w[k];
+      s_logits[sidx] = s_misc[2] * s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 362; i += 256) {
+      out[kOffMoveLogits + i] = s_pi[i];
+      out[kOffOptLogits + i] = s_opt[i];
+    }
+    for (int i = threadIdx.x; i < 800; i += 256) out[kOffScoreLogits + i] = s_logits[i];
+    softmax_block(s_pi, out + kOffMoveProbs, 362, red);
+    softmax_block(s_opt, out + kOffOptProbs, 362, red);
+    softmax_block(s_logits, out + kOffScoreProbs, 800, red);
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(s_misc[0], s_misc[1]);
+      const float e0 = __expf(s_misc[0] - m), e1 = __expf(s_misc[1] - m);
+      out[kOffValueProbs] = e0 / (e0 + e1);
+      out[kOffValueProbs + 1] = e1 / (e0 + e1);
+    }
+    __syncthreads();
+  }
+}
+
+// =======================================================================================
+// Host-side launchers
+// =======================================================================================
+template <int C, int CB, int KIND, int L>
+static hipError_t launch_block_t(const BlockArgs& a, int grid, hipStream_t s) {
+  using G = Geo<128 / CB, CB, 3>;
+  constexpr size_t lds = G::ACT_BYTES + kRingBytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_block<C, CB, KIND, L>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_block<C, CB, KIND, L>), dim3(grid), dim3(kWG), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_block(int C, int kind, int L, const BlockArgs& a, int grid, hipStream_t s) {
+  if (C == 256 && kind == 0 && L == 3) return launch_block_t<256, 128, 0, 3>(a, grid, s);
+  if (C == 256 && kind == 0 && L == 2) return launch_block_t<256, 128, 0, 2>(a, grid, s);
+  if (C == 256 && kind == 0 && L == 1) return launch_block_t<256, 128, 0, 1>(a, grid, s);
+  if (C == 256 && kind == 1) return launch_block_t<256, 128, 1, 2>(a, grid, s);
+  if (C == 128 && kind == 0 && L == 3) return launch_block_t<128, 64, 0, 3>(a, grid, s);
+  if (C == 128 && kind == 0 && L == 2) return launch_block_t<128, 64, 0, 2>(a, grid, s);
+  if (C == 128 && kind == 0 && L == 1) return launch_block_t<128, 64, 0, 1>(a, grid, s);
+  if (C == 128 && kind == 1) return launch_block_t<128, 64, 1, 2>(a, grid, s);
+  return hipErrorInvalidValue;
+}
+
+template <class K>
+static hipError_t set_lds(K kernel, size_t lds) {
+  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+hipError_t launch_init(int C, const InitArgs& a, int grid, hipStream_t s) {
+  using G = Geo<1, 16, 5>;
+  constexpr size_t lds = G::ACT_BYTES + kRingBytes;
+  if (C == 256) {
+    hipLaunchKernelGGL((k_init<256>), dim3(grid), dim3(kWG), lds, s, a);
+  } else if (C == 128) {
+    hipLaunchKernelGGL((k_init<128>), dim3(grid), dim3(kWG), lds, s, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+template <int CIN, int COUT, bool PRE, int EPI>
+static hipError_t launch_conv1x1_t(const Conv1x1Args& a, int grid, hipStream_t s) {
+  constexpr int CB = CIN >= 256 ? 128 : 64;
+  using G = Geo<128 / CB, CB, 1>;
+  constexpr size_t lds = G::ACT_BYTES + kRingBytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = set_lds(k_conv1x1<CIN, COUT, PRE, EPI>, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_conv1x1<CIN, COUT, PRE, EPI>), dim3(grid), dim3(kWG), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipStream_t s) {
+  if (C == 256) {
+    if (which == 0) return launch_conv1x1_t<256, 256, true, 0>(a, grid, s);
+    if (which == 1) return launch_conv1x1_t<256, 256, false, 1>(a, grid, s);
+    if (which == 2) return launch_conv1x1_t<256, 96, false, 2>(a, grid, s);
+  } else if (C == 128) {
+    if (which == 0) return launch_conv1x1_t<128, 128, true, 0>(a, grid, s);
+    if (which == 1) return launch_conv1x1_t<128, 128, false, 1>(a, grid, s);
+    if (which == 2) return launch_conv1x1_t<128, 96, false, 2>(a, grid, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s) {
+  constexpr size_t lds = 128 * kTtStride + kRingBytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = set_lds(k_bdense<256>, lds);
+    if (e == hipSuccess) e = set_lds(k_bdense<128>, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (C == 256) {
+    hipLaunchKernelGGL((k_bdense<256>), dim3(grid), dim3(kWG), lds, s, a);
+  } else if (C == 128) {
+    hipLaunchKernelGGL((k_bdense<128>), dim3(grid), dim3(kWG), lds, s, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_heads(const HeadsArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((k_heads<32>), dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+const char* block_kernel_name(int C, int kind, int L) {
+  (void)L;
+  if (kind == 0) return C == 256 ? "k_block<256,128,btl>" : "k_block<128,64,btl>";
+  return C == 256 ? "k_block<256,128,nbt>" : "k_block<128,64,nbt>";
+}
+
+}  // namespace p3

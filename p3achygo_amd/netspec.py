@@ -71,9 +71,11 @@ CONFIGS: Dict[str, NetConfig] = {
         NetConfig("b8c128nbt", 8, 128, 64, 32, 64, 3, 2, "nbt"),
         NetConfig("b12c256nbt", 12, 256, 128, 32, 80, 3, 2, "nbt"),
         NetConfig("b10c384nbt", 10, 384, 192, 32, 80, 4, 2, "nbt"),
-        # not in the reference: a small net with MFMA-friendly widths for fast GPU parity tests
-        NetConfig("test_b4c64btl2", 4, 64, 32, 32, 32, 3, 2, "btl"),
-        NetConfig("test_b3c64nbt", 3, 64, 32, 32, 32, 3, 2, "nbt"),
+        # not in the reference: shallow nets of the supported widths for fast parity tests
+        NetConfig("test_b3c128btl2", 3, 128, 64, 32, 32, 3, 2, "btl"),
+        NetConfig("test_b3c128nbt", 3, 128, 64, 32, 48, 3, 2, "nbt"),
+        NetConfig("test_b3c256btl1", 3, 256, 128, 32, 64, 3, 1, "btl"),
+        NetConfig("test_b3c256nbt", 3, 256, 128, 32, 80, 3, 2, "nbt"),
     ]
 }
 

@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: b12c256btl3 policy/value-net evaluation of leaf positions.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the engine's forward path (init conv -> 12 residual blocks ->
+heads) over one batch of 1024 synthetic 19x19 positions per GPU (BASELINE.json configs[2]:
+"v3-b12c256btl3 on 1 MI355X, 1024 concurrent games, batch=1024, fp16"), inputs already
+resident in HBM when the timed region starts.  Games shard embarrassingly across GPUs
+(one engine + one HIP stream per device, no collective on the data path), so scaling is
+weak: every rank evaluates its own 1024 positions.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel k_block: 3x3-conv FLOPs per
+launch / HIP-event time, against the 2.5 PFLOP/s dense fp16 MFMA peak) and `cpu_baseline`
+(the CPU fp32 oracle timed on this box's host cores over a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+MODEL = "b12c256btl3"
+BATCH = 1024
+PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 PF
+
+
+def make_positions(n, seed):
+    from p3achygo_amd import features
+    base = features.random_positions(64, seed=seed, n_games=16)
+    reps = (n + len(base) - 1) // len(base)
+    return np.tile(base, reps)[:n].copy()
+
+
+def cpu_baseline(path, pos, budget_s=12.0):
+    """CPU fp32 oracle (oracle/nn_oracle.c, a port: the reference TF-CPU engine is stale and
+    unbuildable) on all host cores, bounded to ~budget_s seconds."""
+    from oracle import oracle
+    # the GPU box gives a 1-GPU job a 16-CPU share; never oversubscribe it
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    net = oracle.OracleNet(path)
+    t0 = time.perf_counter()
+    net.forward_features(pos[:cores], nthreads=cores)
+    t1 = time.perf_counter() - t0
+    rounds = max(1, min(8, int(budget_s / max(t1, 1e-3))))
+    n = cores * rounds
+    sample = pos[np.arange(n) % len(pos)]
+    t0 = time.perf_counter()
+    net.forward_features(sample, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "positions/s", "cores": cores, "kind": "port",
+            "sample": f"{n} positions of the same batch, {MODEL} fp32 direct conv, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--model", default=MODEL)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    n_gpus = max(world, 1)
+
+    from p3achygo_amd import engine, netspec
+    cfg = netspec.CONFIGS[args.model]
+    tmp = tempfile.mkdtemp(prefix="p3bench")
+    path = os.path.join(tmp, f"{args.model}.p3w")
+    netspec.save_p3w(path, cfg, netspec.generate_weights(cfg))  # fresh-Keras random init
+    pos = make_positions(args.batch, seed=1000 + rank)
+
+    torch.cuda.set_device(local_rank)
+    eng = engine.create_engine(engine.kind_from_engine_path(path), path, args.batch, 1,
+                               device=local_rank)
+    eng.load_all(pos)
+    eng.upload()  # inputs resident in HBM before the timed region
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.forward_resident(args.batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.forward_resident(args.batch)
+    eng.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+        dist.barrier()
+
+    total_flops, conv3_flops = eng.flops_per_position()
+    roof = None
+    cpu = None
+    if rank == 0:
+        ms, flops_launch, kname = eng.time_trunk_kernel(args.batch, 10)
+        achieved = flops_launch / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": kname, "achieved": achieved,
+                "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": None,
+                "launch_ms": ms, "algorithmic_flops_per_launch": flops_launch}
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(path, pos)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        pps = n_gpus * args.batch * args.steps / dt
+        out = {
+            "metric": "self-play positions/sec at 1/8 MI355X, b12c256btl3 19x19 n=32",
+            "value": pps, "unit": "positions/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{args.model} random-init, NN evaluation of {args.batch} "
+                                   "leaf positions per GPU per step (engine forward, inputs "
+                                   "resident in HBM; leaf positions from seeded random-legal "
+                                   "playouts)",
+                       "batch_per_gpu": args.batch, "parallelism": f"games sharded x{n_gpus}, no collective"},
+            "full_net_tflops": pps * total_flops / 1e12,
+            "conv3x3_mfma_frac_end_to_end": pps * conv3_flops / 1e12 / (PEAK_FP16_MFMA_TFLOPS * n_gpus),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

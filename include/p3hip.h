@@ -132,6 +132,10 @@ int p3hip_get_raw(p3hip_engine* e, int slot, float* out);
  * number of positions one launch processed and its 3x3-conv FLOPs. */
 double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
                                double* flops_per_launch, const char** kernel_name);
+/* Diagnostic build of the fused block kernel with in-kernel s_memtime stamps at phase
+ * boundaries (C=256 btl3 nets only).  Returns the grid size (>0) or <=0 on error. */
+int p3hip_debug_block_stamps(p3hip_engine* e, int n_positions, unsigned long long* out,
+                             int max_u64);
 /* Algorithmic FLOPs (2*MAC) of one position: total, and 3x3 trunk convs only. */
 void p3hip_flops_per_position(const p3hip_engine* e, double* total, double* conv3x3);
 

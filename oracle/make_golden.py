@@ -74,8 +74,8 @@ def dump_nn(name, n_pos, seed):
         sc[k, 0 if col == 1 else 1] = 1
         sc[k, 7] = (-1.0 if col == 1 else 1.0) * float(f["komi"]) / 15.0
     ref = tr.forward(cfg, W, planes, sc)
-    wsum = float(sum(float(np.float64(w).sum()) for w in W.values()))
-    wsq = float(sum(float((np.float64(w) ** 2).sum()) for w in W.values()))
+    wsum = float(sum(float(w.astype(np.float64).sum()) for w in W.values()))
+    wsq = float(sum(float((w.astype(np.float64) ** 2).sum()) for w in W.values()))
     np.savez_compressed(
         os.path.join(GOLD, f"nn_{name}.npz"),
         features=np.frombuffer(pos.tobytes(), np.uint8), n_pos=n_pos, planes=planes.astype(np.uint8),

@@ -35,10 +35,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWG = 512;          // threads per workgroup (8 waves)
 constexpr int kNLoc = 361;
 constexpr int kBL = 19;
-constexpr int kRingSlotBytes = 8192;
-constexpr int kRingSlots = 5;     // R
-constexpr int kRingDepth = 3;     // D = R - 2 (see ring_acquire)
-constexpr int kRingBytes = kRingSlots * kRingSlotBytes;
+constexpr int kKMS = 4;           // k16-steps (K = 64) per ring macro-step
+constexpr int kRingSlots = 3;     // R
+constexpr int kRingDepth = 2;     // D = R - 1 (see ring_acquire)
+// bytes of one macro-step for a COUT_PASS-wide weight panel: kKMS blocks of [2][CP][8] fp16
+constexpr int ring_slot_bytes(int cout_pass) { return kKMS * cout_pass * 32; }
+constexpr int ring_bytes(int cout_pass) { return kRingSlots * ring_slot_bytes(cout_pass); }
 
 // ---------------------------------------------------------------------------------------
 // Geometry of one conv "space": NPOS positions, NT_TOTAL 32-wide location tiles each.
@@ -82,55 +84,93 @@ __device__ __forceinline__ float mish_f(float x) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Weight ring.
+// Weight ring.  RS = bytes per macro-step (16 KiB for 128-wide panels, 8 KiB for 64-wide);
+// each of the 8 waves copies RS/8 bytes (G = RS/8192 glds of 1 KiB) per macro-step.
+template <int RS>
 struct Ring {
-  const char* gbase;   // packed stream (global), nms_total macro-steps of 8 KiB
+  static constexpr int G = RS / 8192;
+  static_assert(G == 1 || G == 2, "ring slot size");
+  const char* gbase;   // packed stream (global), nms_total macro-steps of RS bytes
   int nms_total;
   uint32_t lds_base;   // byte offset of the ring inside the dynamic LDS array
   int pf;              // next stream macro-step to prefetch (circular)
   int pf_slot;
   int slot;            // ring slot of the next macro-step to consume
+  int tol;             // acquires left that must tolerate kXLoads younger register loads
+  unsigned long long wait_cycles;  // diagnostic builds: cycles spent in ring_acquire waits
 };
 
-__device__ __forceinline__ void ring_issue(Ring& r, char* smem) {
+// Register prefetch of the next activation slice: every thread issues exactly kXLoads
+// 16-byte global loads (see stage_load) while the ring keeps streaming.
+constexpr int kXLoads = 12;
+
+template <int RS>
+__device__ __forceinline__ void ring_issue(Ring<RS>& r, char* smem) {
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const char* gp = r.gbase + (size_t)r.pf * kRingSlotBytes + wid * 1024 + lane * 16;
-  char* lp = smem + r.lds_base + r.pf_slot * kRingSlotBytes + wid * 1024;
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                   (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+  const char* gp = r.gbase + (size_t)r.pf * RS + wid * (RS / 8) + lane * 16;
+  char* lp = smem + r.lds_base + r.pf_slot * RS + wid * (RS / 8);
+#pragma unroll
+  for (int i = 0; i < Ring<RS>::G; ++i)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + i * 1024),
+                                     (__attribute__((address_space(3))) void*)(lp + i * 1024), 16, 0, 0);
   r.pf = (r.pf + 1 == r.nms_total) ? 0 : r.pf + 1;
   r.pf_slot = (r.pf_slot + 1 == kRingSlots) ? 0 : r.pf_slot + 1;
 }
 
-__device__ __forceinline__ void ring_init(Ring& r, char* smem, const void* gbase, int nms_total,
-                                          uint32_t lds_base) {
+template <int RS>
+__device__ __forceinline__ void ring_init(Ring<RS>& r, char* smem, const void* gbase,
+                                          int nms_total, uint32_t lds_base) {
   r.gbase = (const char*)gbase;
   r.nms_total = nms_total;
   r.lds_base = lds_base;
   r.pf = 0;
   r.pf_slot = 0;
   r.slot = 0;
+  r.tol = 0;
+  r.wait_cycles = 0;
   for (int i = 0; i < kRingDepth; ++i) ring_issue(r, smem);
 }
 
 // Makes the next macro-step readable and returns its LDS byte offset.
-// Invariant on entry: this wave has exactly D glds in flight (for macro-steps m..m+D-1),
+// Invariant on entry: this wave has exactly D*G glds in flight (macro-steps m..m+D-1),
 // possibly followed by younger ordinary loads/stores (which only make the wait stricter).
-// vmcnt(D-1) => piece m of this wave landed; the barrier => every wave's piece landed, and
-// every wave has consumed macro-step m-2 completely, whose slot ((m+D) mod R with R = D+2)
-// is the one refilled below.  lgkmcnt(0) also retires this wave's LDS writes, so the
-// barrier doubles as the "epilogue written" barrier between layers.
-__device__ __forceinline__ uint32_t ring_acquire(Ring& r, char* smem) {
-  static_assert(kRingDepth == 3, "vmcnt immediate below assumes D == 3");
-  asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+// vmcnt((D-1)*G) => this wave's pieces of m landed; the barrier => every wave's pieces
+// landed.  lgkmcnt(0) retires this wave's LDS reads and writes: every fragment read of
+// macro-step m-1 has completed in every wave once the barrier is passed (the last k16 of
+// m-1 is fetched into registers before this call), so its slot ((m+D) mod R, R = D+1) can
+// be refilled below; the same wait makes the barrier double as the "epilogue written"
+// barrier between layers.
+// While ring.tol > 0 the wave also has kXLoads register loads in flight that were issued
+// right after the D*G glds (ring_note_xloads): for the next D acquires the pieces that must
+// have landed are still older than all of them, so the count to leave outstanding is
+// (D-1)*G + kXLoads; the (D+1)-th acquire waits with vmcnt((D-1)*G) again, which retires them.
+template <bool STAMPS = false, int RS = 0>
+__device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
+  static_assert(kRingDepth == 2 && kXLoads == 12, "vmcnt immediates below");
+  unsigned long long t0 = 0;
+  if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
+  if (r.tol > 0) {
+    if (Ring<RS>::G == 2) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory");
+    r.tol--;
+  } else {
+    if (Ring<RS>::G == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if (STAMPS) r.wait_cycles += __builtin_amdgcn_s_memtime() - t0;
   ring_issue(r, smem);
-  uint32_t off = r.lds_base + r.slot * kRingSlotBytes;
+  uint32_t off = r.lds_base + r.slot * RS;
   r.slot = (r.slot + 1 == kRingSlots) ? 0 : r.slot + 1;
   return off;
 }
+
+// Call right after issuing the kXLoads prefetch loads (and nothing else since the last
+// ring_issue).
+template <int RS>
+__device__ __forceinline__ void ring_note_xloads(Ring<RS>& r) { r.tol = kRingDepth; }
 
 __device__ __forceinline__ void ring_drain() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -151,7 +191,8 @@ struct Tiling {
   static constexpr int LG = 8 / CG;
   static constexpr int MT = 2;
   static constexpr int NT = (G::NT_TOTAL + LG - 1) / LG;
-  static constexpr int KMS = kRingSlotBytes / (COUT_PASS * 32);  // k16-steps per macro-step
+  static constexpr int KMS = kKMS;                  // k16-steps per macro-step
+  static constexpr int RS = ring_slot_bytes(COUT_PASS);
   static_assert(CG * LG == 8 && (CG == 1 || CG == 2), "tiling");
 };
 
@@ -166,13 +207,20 @@ __device__ __forceinline__ int tile_slot0(int t) {
 // One conv segment: acc[mt][j] += W_seg x act over NK16 k16-steps taken in the order
 // (tap major, channel-chunk-pair minor).  KW = kernel width (1, 3 or 5); NTAPS_PAD is the
 // number of taps in the packed stream (>= KW*KW, zero weights beyond).
-template <class G, int COUT_PASS, int KW, int NTAPS_PAD, int NTn>
-__device__ __forceinline__ void conv_segment(Ring& ring, char* smem, f32x16 (&acc)[2][NTn]) {
+// Loop shape: a runtime outer loop whose body is U = max(NQ, KMS) fully unrolled k16-steps,
+// fragments double-buffered by the (static) parity of the step, next step's fragments
+// (and, every KMS steps, the next ring slot) fetched before the current step's MFMAs.
+template <class G, int COUT_PASS, int KW, int NTAPS_PAD, bool STAMPS = false, int NTn = 0>
+__device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS)>& ring, char* smem,
+                                             f32x16 (&acc)[2][NTn]) {
   using T = Tiling<G, COUT_PASS>;
   static_assert(NTn == T::NT, "accumulator shape");
   constexpr int NQ = G::CB / 16;                 // k16-steps per tap
   constexpr int NK16 = NTAPS_PAD * NQ;
-  static_assert(NK16 % T::KMS == 0, "segment must be whole macro-steps");
+  constexpr int U = NQ > T::KMS ? NQ : T::KMS;   // unrolled body length
+  constexpr int NOUT = NK16 / U;
+  constexpr int TPB = U / NQ;                    // taps per body (>1 only when NQ < KMS)
+  static_assert(NK16 % U == 0 && U % T::KMS == 0 && U % NQ == 0 && U % 2 == 0, "segment shape");
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cg = wid % T::CG, lg = wid / T::CG;
@@ -188,46 +236,62 @@ __device__ __forceinline__ void conv_segment(Ring& ring, char* smem, f32x16 (&ac
   // A fragment offset inside a k16 block: [h][cout][8] fp16
   const uint32_t a_off = (uint32_t)((h * COUT_PASS + cg * 64 + lr) * 16);
 
-  uint32_t wslot = 0;
-  h8 a_cur[2], b_cur[T::NT];
-  auto load_frags = [&](int g, h8 (&a)[2], h8 (&b)[T::NT]) {
-    const int tap = g / NQ, q = g - tap * NQ;
+  // per-tap B addressing: byte base of the shifted slot and its swizzle
+  struct TapAddr { uint32_t base[T::NT]; int sw[T::NT]; };
+  auto tap_addr = [&](int tap, TapAddr& ta) {
     int shift = 0;
     if (KW > 1) {
-      int ky = tap / KW, kx = tap - ky * KW;
+      const int ky = tap / KW, kx = tap - ky * KW;
       shift = (tap < KW * KW) ? (ky - KW / 2) * G::S + (kx - KW / 2) : 0;
     }
-    const uint32_t wk = wslot + (uint32_t)((g % T::KMS) * (COUT_PASS * 32));
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) a[mt] = *(const h8*)(smem + wk + a_off + mt * 512);
 #pragma unroll
     for (int j = 0; j < T::NT; ++j) {
-      int s = slot0[j] + shift;
-      int ch = (2 * q + h) ^ swz<G::NCH>(s);
-      b[j] = *(const h8*)(smem + s * G::SLOTB + ch * 16);
+      const int sl = slot0[j] + shift;
+      ta.base[j] = (uint32_t)(sl * G::SLOTB);
+      ta.sw[j] = swz<G::NCH>(sl);
     }
   };
+  h8 fa[2][2], fb[2][T::NT];
+  uint32_t wslot = 0;
+  // u = static step index inside the body; q = u % NQ is static too
+  auto load_frags = [&](const TapAddr& ta, int u, int buf) {
+    const int q = u % NQ;
+    const uint32_t wk = wslot + (uint32_t)((u % T::KMS) * (COUT_PASS * 32));
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) fa[buf][mt] = *(const h8*)(smem + wk + a_off + mt * 512);
+#pragma unroll
+    for (int j = 0; j < T::NT; ++j)
+      fb[buf][j] = *(const h8*)(smem + ta.base[j] + (((2 * q + h) ^ ta.sw[j]) << 4));
+  };
 
-  wslot = ring_acquire(ring, smem);
-  load_frags(0, a_cur, b_cur);
-#pragma unroll 2
-  for (int g = 0; g < NK16; ++g) {
-    h8 a_nxt[2], b_nxt[T::NT];
-    if (g + 1 < NK16) {
-      if (((g + 1) % T::KMS) == 0) wslot = ring_acquire(ring, smem);
-      load_frags(g + 1, a_nxt, b_nxt);
+  TapAddr cur[TPB], nxt[TPB];
+#pragma unroll
+  for (int t = 0; t < TPB; ++t) tap_addr(t, cur[t]);
+  wslot = ring_acquire<STAMPS>(ring, smem);
+  load_frags(cur[0], 0, 0);
+#pragma unroll 1
+  for (int o = 0; o < NOUT; ++o) {
+    if (o + 1 < NOUT) {
+#pragma unroll
+      for (int t = 0; t < TPB; ++t) tap_addr((o + 1) * TPB + t, nxt[t]);
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int u = 0; u < U; ++u) {
+      if (u + 1 < U) {
+        if (((u + 1) % T::KMS) == 0) wslot = ring_acquire<STAMPS>(ring, smem);
+        load_frags(cur[(u + 1) / NQ], u + 1, (u + 1) & 1);
+      } else if (o + 1 < NOUT) {
+        wslot = ring_acquire<STAMPS>(ring, smem);
+        load_frags(nxt[0], 0, 0);
+      }
 #pragma unroll
-      for (int j = 0; j < T::NT; ++j)
-        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[mt], b_cur[j], acc[mt][j], 0, 0, 0);
-    if (g + 1 < NK16) {
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) a_cur[mt] = a_nxt[mt];
-#pragma unroll
-      for (int j = 0; j < T::NT; ++j) b_cur[j] = b_nxt[j];
+        for (int j = 0; j < T::NT; ++j)
+          acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u & 1][mt], fb[u & 1][j], acc[mt][j], 0, 0, 0);
     }
+#pragma unroll
+    for (int t = 0; t < TPB; ++t) cur[t] = nxt[t];
   }
 }
 
@@ -289,42 +353,76 @@ __device__ __forceinline__ void epilogue_to_act(char* smem, f32x16 (&acc)[2][NTn
   }
 }
 
-// Stage a CB-channel slice (channel blocks cblk0 .. cblk0+NCH-1) of the residual stream
-// x[pos][C/8][361][8] (fp16) into the act buffer, applying y = mish(x*scale+shift)
-// when PRE is set.  Only valid locations are written; pad slots stay zero.
+// Staging of a CB-channel slice (channel blocks cblk0 .. cblk0+NCH-1) of the residual
+// stream x[pos][C/8][361][8] (fp16) into the act buffer, split in two so that the HBM/L2
+// latency hides under MFMA work: stage_load issues this thread's kXLoads 16-byte loads
+// into registers, stage_store applies y = mish(x*scale+shift) (when PRE) and writes the
+// swizzled LDS image.  Only valid locations are written; pad slots stay zero.
+template <class G>
+struct XRegs { h8 v[kXLoads]; };
+
+// Thread t owns (position, chunk) combo t/32 and board points (t%32) + 32*i, i < 12
+// (12*32 = 384 >= 361), so its BN parameters are loaded once and addressing is trivial.
+template <class G>
+__device__ __forceinline__ void stage_load(XRegs<G>& xr, const _Float16* __restrict__ x, int C,
+                                           int pos0, int npos, int cblk0) {
+  static_assert(G::NPOS * G::NCH == 16 && kXLoads * 32 >= kNLoc, "staging map");
+  const int combo = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+  const int p = combo / G::NCH, kc = combo - p * G::NCH;
+  int pos = pos0 + p;
+  if (pos >= npos) pos = npos - 1;
+  const _Float16* src = x + ((size_t)pos * (C / 8) + cblk0 + kc) * (kNLoc * 8);
+#pragma unroll
+  for (int i = 0; i < kXLoads; ++i) {
+    int loc = l32 + 32 * i;
+    if (loc >= kNLoc) loc = kNLoc - 1;  // tail lanes re-read a valid item (not stored)
+    xr.v[i] = *(const h8*)(src + loc * 8);
+  }
+}
+
 template <class G, bool PRE>
-__device__ __forceinline__ void stage_in(char* smem, const _Float16* __restrict__ x, int C,
-                                         int pos0, int npos, int cblk0,
-                                         const float* __restrict__ scale,
-                                         const float* __restrict__ shift) {
-  constexpr int ITEMS = G::NPOS * G::NCH * kNLoc;
-  for (int it = threadIdx.x; it < ITEMS; it += kWG) {
-    const int p = it / (G::NCH * kNLoc);
-    const int rem = it - p * (G::NCH * kNLoc);
-    const int kc = rem / kNLoc;
-    const int loc = rem - kc * kNLoc;
-    int pos = pos0 + p;
-    if (pos >= npos) pos = npos - 1;
-    const h8 v = *(const h8*)(x + ((size_t)pos * (C / 8) + cblk0 + kc) * (kNLoc * 8) + loc * 8);
+__device__ __forceinline__ void stage_store(char* smem, const XRegs<G>& xr, int cblk0,
+                                            const float* __restrict__ scale,
+                                            const float* __restrict__ shift) {
+  const int combo = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+  const int p = combo / G::NCH, kc = combo - p * G::NCH;
+  f32x4 s0, s1, t0, t1;
+  if (PRE) {
+    const int c = (cblk0 + kc) * 8;
+    s0 = *(const f32x4*)(scale + c); s1 = *(const f32x4*)(scale + c + 4);
+    t0 = *(const f32x4*)(shift + c); t1 = *(const f32x4*)(shift + c + 4);
+  }
+#pragma unroll
+  for (int i = 0; i < kXLoads; ++i) {
+    const int loc = l32 + 32 * i;
+    if (loc >= kNLoc) continue;
+    const h8 v = xr.v[i];
     h8 o;
     if (PRE) {
-      const int c = (cblk0 + kc) * 8;
-      const f32x4 s0 = *(const f32x4*)(scale + c), s1 = *(const f32x4*)(scale + c + 4);
-      const f32x4 t0 = *(const f32x4*)(shift + c), t1 = *(const f32x4*)(shift + c + 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        o[i] = (_Float16)mish_f((float)v[i] * s0[i] + t0[i]);
-        o[i + 4] = (_Float16)mish_f((float)v[i + 4] * s1[i] + t1[i]);
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (_Float16)mish_f((float)v[e] * s0[e] + t0[e]);
+        o[e + 4] = (_Float16)mish_f((float)v[e + 4] * s1[e] + t1[e]);
       }
     } else {
       o = v;
     }
     const int y = (loc * 3450) >> 16;  // loc / 19 for loc < 361
     const int xx = loc - y * kBL;
-    const int s = p * G::PSLOTS + G::PADTOP + y * G::S + xx;
-    const int ch = kc ^ swz<G::NCH>(s);
-    *(h8*)(smem + s * G::SLOTB + ch * 16) = o;
+    const int sl = p * G::PSLOTS + G::PADTOP + y * G::S + xx;
+    const int ch = kc ^ swz<G::NCH>(sl);
+    *(h8*)(smem + sl * G::SLOTB + ch * 16) = o;
   }
+}
+
+template <class G, bool PRE>
+__device__ __forceinline__ void stage_in(char* smem, const _Float16* __restrict__ x, int C,
+                                         int pos0, int npos, int cblk0,
+                                         const float* __restrict__ scale,
+                                         const float* __restrict__ shift) {
+  XRegs<G> xr;
+  stage_load<G>(xr, x, C, pos0, npos, cblk0);
+  stage_store<G, PRE>(smem, xr, cblk0, scale, shift);
 }
 
 template <class G>
@@ -333,7 +431,9 @@ __device__ __forceinline__ void act_zero(char* smem) {
 }
 
 // Epilogue B: out[c][loc] = acc (+ residual read from the same place) -> fp16 global, in
-// the channel-blocked layout.  cofs = first channel of this cout pass.
+// the channel-blocked layout.  cofs = first channel of this cout pass.  All residual
+// loads are issued before the first store (loads and stores go through the same pointer,
+// so the compiler would otherwise serialise load -> store -> load on possible aliasing).
 template <class G, int COUT_PASS, bool RESIDUAL, int NTn>
 __device__ __forceinline__ void epilogue_to_global(f32x16 (&acc)[2][NTn],
                                                    _Float16* __restrict__ x, int C, int pos0,
@@ -343,34 +443,40 @@ __device__ __forceinline__ void epilogue_to_global(f32x16 (&acc)[2][NTn],
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lg = wid / T::CG;
   const int lr = lane & 31, h = lane >> 5;
+  const int c0 = cofs + acc_chan<G, COUT_PASS>(0, 0);   // channel of (mt=0, g4=0)
+  size_t base[NTn];
+  bool ok[NTn];
 #pragma unroll
-  for (int j = 0; j < T::NT; ++j) {
+  for (int j = 0; j < NTn; ++j) {
     const int t = lg + j * T::LG;
-    if (t >= G::NT_TOTAL) continue;
-    const int p = t / G::NT_POS, tt = t - p * G::NT_POS;
-    const int r = tt * 32 + lr;
+    const int tv = t < G::NT_TOTAL ? t : lg;
+    const int p = tv / G::NT_POS, tt = tv - p * G::NT_POS;
     int loc;
-    const bool ok = row_valid<G::S>(r, loc) && (pos0 + p < npos);
-    if (!ok) continue;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int c = cofs + acc_chan<G, COUT_PASS>(mt, g4);
-        _Float16* px = x + ((size_t)(pos0 + p) * (C / 8) + (c >> 3)) * (kNLoc * 8) + loc * 8 + h * 4;
-        h4 o;
-        if (RESIDUAL) {
-          const h4 rv = *(const h4*)px;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = (_Float16)(acc[mt][j][g4 * 4 + i] + (float)rv[i]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = (_Float16)acc[mt][j][g4 * 4 + i];
-        }
-        *(h4*)px = o;
-      }
-    }
+    ok[j] = row_valid<G::S>(tt * 32 + lr, loc) && (pos0 + p < npos) && (t < G::NT_TOTAL);
+    base[j] = ((size_t)(pos0 + p) * (C / 8) + (c0 >> 3)) * (kNLoc * 8) + loc * 8 + h * 4;
   }
+  h4 rv[NTn][8];
+  if (RESIDUAL) {
+#pragma unroll
+    for (int j = 0; j < NTn; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)   // k = mt*4 + g4: channel block c0/8 + k
+        if (ok[j]) rv[j][k] = *(const h4*)(x + base[j] + (size_t)k * (kNLoc * 8));
+  }
+#pragma unroll
+  for (int j = 0; j < NTn; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int mt = k >> 2, g4 = k & 3;
+      h4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[mt][j][g4 * 4 + i];
+        if (RESIDUAL) v += (float)rv[j][k][i];
+        o[i] = (_Float16)v;
+      }
+      if (ok[j]) *(h4*)(x + base[j] + (size_t)k * (kNLoc * 8)) = o;
+    }
 }
 
 }  // namespace p3

@@ -192,9 +192,12 @@ FoldedBN fold_bn(Arena& ar, const WeightFile& wf, const std::string& prefix) {
   return f;
 }
 
-size_t add_stream(Arena& ar, const std::vector<_Float16>& s, int& nms) {
-  if (s.size() * 2 % 8192 != 0) { fprintf(stderr, "p3hip: stream not macro-step aligned\n"); abort(); }
-  nms = (int)(s.size() * 2 / 8192);
+// A stream is a whole number of macro-steps of 4 k16 blocks = cout_pass * 128 bytes
+// (conv_core.h ring_slot_bytes).
+size_t add_stream(Arena& ar, const std::vector<_Float16>& s, int& nms, int cout_pass) {
+  const size_t ms = (size_t)cout_pass * 128;
+  if (s.size() * 2 % ms != 0) { fprintf(stderr, "p3hip: stream not macro-step aligned\n"); abort(); }
+  nms = (int)(s.size() * 2 / ms);
   return ar.add(s.data(), s.size() * 2);
 }
 
@@ -212,8 +215,8 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
     std::vector<_Float16> s;
     const Tensor& w = wf.get("init_conv.w");  // [5][5][15][C]
     for (int cp = 0; cp < C / 128; ++cp)
-      pack_segment(s, w.data, 25, 26, 15, C, 0, 16, cp * 128, 128);
-    e->init_stream_off = add_stream(ar, s, e->init_nms);
+      pack_segment(s, w.data, 25, 28, 15, C, 0, 16, cp * 128, 128);
+    e->init_stream_off = add_stream(ar, s, e->init_nms, 128);
     e->game_w_off = ar.add(wf.get("init_game.w").data, 8 * C * 4);
     e->game_b_off = ar.add(wf.get("init_game.b").data, C * 4);
   }
@@ -242,9 +245,9 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
                 float v = (ii < kNLoc && j < kNLoc) ? dw.data[(size_t)ii * kNLoc + j] : 0.0f;
                 s1.push_back((_Float16)v);
               }
-      bp.stream_off = add_stream(ar, s0, bp.nms);
-      bp.stream2_off = add_stream(ar, s1, bp.nms2);
-      bp.stream3_off = add_stream(ar, s2, bp.nms3);
+      bp.stream_off = add_stream(ar, s0, bp.nms, CPb);
+      bp.stream2_off = add_stream(ar, s1, bp.nms2, 128);
+      bp.stream3_off = add_stream(ar, s2, bp.nms3, CPb);
       bp.dense_bias_off = ar.add(wf.get(p + ".dense.b").data, kNLoc * 4);
     } else {
       bp.kind = wf.btype;
@@ -254,7 +257,7 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
       for (int ip = 0; ip < C / CB; ++ip) pack_segment(s, W(0), 1, 1, C, Cb, ip * CB, CB, 0, CB);
       for (int j = 1; j < nconv - 1; ++j) pack_segment(s, W(j), 9, 9, Cb, Cb, 0, CB, 0, CB);
       for (int cp = 0; cp < C / CB; ++cp) pack_segment(s, W(nconv - 1), 1, 1, Cb, C, 0, CB, cp * CB, CB);
-      bp.stream_off = add_stream(ar, s, bp.nms);
+      bp.stream_off = add_stream(ar, s, bp.nms, CB);
     }
     e->blocks.push_back(bp);
   }
@@ -273,7 +276,7 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
     std::vector<_Float16> s;
     for (int cp = 0; cp < 2; ++cp)
       for (int ip = 0; ip < C / CB; ++ip) pack_segment(s, w.data(), 1, 1, C, 96, ip * CB, CB, cp * 64, 64);
-    e->heads_stream_off = add_stream(ar, s, e->heads_nms);
+    e->heads_stream_off = add_stream(ar, s, e->heads_nms, 64);
     FoldedBN g = fold_bn(ar, wf, "policy.gpool_bn");
     e->head_off["gbn_scale"] = g.scale_off;
     e->head_off["gbn_shift"] = g.shift_off;
@@ -550,6 +553,29 @@ void p3hip_flops_per_position(const p3hip_engine* e, double* total, double* conv
          (2 * H + 1) * V + 800 * V;
   if (total) *total = 2.0 * (mac + mac3);
   if (conv3x3) *conv3x3 = 2.0 * mac3;
+}
+
+// Diagnostic: runs the first btl block (C=256, L=3 only) with in-kernel phase stamps.
+// out receives grid*2*4*32 u64 (workgroup, wave {0,7}, position index, stamp id).
+int p3hip_debug_block_stamps(p3hip_engine* e, int n_positions, unsigned long long* out, int max_u64) {
+  const WeightFile& wf = e->wf;
+  const BlockPlan* bp = nullptr;
+  for (const BlockPlan& b : e->blocks)
+    if (b.kind == 0) { bp = &b; break; }
+  if (!bp || wf.C != 256 || wf.inner != 3) { e->err = "stamps: need a C=256 btl3 net"; return 1; }
+  const int grid = grid_for(e, n_positions, 1);
+  const size_t n = (size_t)grid * 2 * 4 * 32;
+  if ((size_t)max_u64 < n) { e->err = "stamps: buffer too small"; return 1; }
+  unsigned long long* d = nullptr;
+  if (!e->check(hipMalloc((void**)&d, n * 8), "hipMalloc stamps")) return 1;
+  hipMemsetAsync(d, 0, n * 8, e->stream);
+  p3::BlockArgs a = block_args(e, *bp, n_positions);
+  a.stamps = d;
+  bool ok = e->check(p3::launch_block_stamps(a, grid, e->stream), "launch stamps") &&
+            e->check(hipStreamSynchronize(e->stream), "sync") &&
+            e->check(hipMemcpy(out, d, n * 8, hipMemcpyDeviceToHost), "D2H stamps");
+  hipFree(d);
+  return ok ? grid : -1;
 }
 
 double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,

@@ -31,6 +31,7 @@ struct BlockArgs {
   int nms_total;        // its length in 8 KiB macro-steps
   const float* scale[kMaxBlockLayers];  // folded BN of conv j's prologue
   const float* shift[kMaxBlockLayers];
+  unsigned long long* stamps;  // diagnostic build only
 };
 
 struct InitArgs {
@@ -86,6 +87,7 @@ struct HeadsArgs {
 };
 
 hipError_t launch_block(int C, int kind, int L, const BlockArgs& a, int grid, hipStream_t s);
+hipError_t launch_block_stamps(const BlockArgs& a, int grid, hipStream_t s);
 hipError_t launch_init(int C, const InitArgs& a, int grid, hipStream_t s);
 // which: 0 = broadcast conv_first (bn+mish prologue, mish epilogue), 1 = broadcast
 // conv_last (+residual), 2 = head convs (fp32 out, COUT = 96)

@@ -24,7 +24,17 @@ namespace p3 {
 //   reduce: for each CB-slice of C input channels; inner 3x3 convs in order; expand: for
 //   each CB-slice of C output channels.
 // =======================================================================================
-template <int C, int CB, int KIND, int L>
+// STAMPS: diagnostic build only (p3hip_debug_block_stamps): lane 0 of waves 0 and 7 of every
+// workgroup stores s_memtime at each phase boundary into a.stamps (never read by the kernel).
+#define P3_STAMP(k)                                                                          \
+  if (STAMPS) {                                                                              \
+    const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                         \
+    if ((threadIdx.x & 63) == 0 && (w_ == 0 || w_ == 7) && npos_done < 4)                   \
+      a.stamps[((blockIdx.x * 2 + (w_ == 7)) * 4 + npos_done) * 32 + (k)] =                  \
+          __builtin_amdgcn_s_memtime();                                                      \
+  }
+
+template <int C, int CB, int KIND, int L, bool STAMPS = false>
 __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
   constexpr int NPOS = 128 / CB;
   using G = Geo<NPOS, CB, 3>;
@@ -33,30 +43,48 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
   constexpr uint32_t kRingOff = G::ACT_BYTES;
 
   act_zero<G>(smem);
-  Ring ring;
+  Ring<T::RS> ring;
   ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
   lds_barrier();
 
-  for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS) {
+  static_assert(C / CB == 2, "two input slices / two output passes");
+  XRegs<G> xr;
+  stage_load<G>(xr, a.x, C, blockIdx.x * NPOS, a.npos, 0);
+  int npos_done = 0;
+  for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS, ++npos_done) {
     f32x16 acc[2][T::NT];
-    // ---- reduce 1x1 (C -> CB), prologue bn0+mish applied while staging --------------
+    P3_STAMP(0);
+    // ---- reduce 1x1 (C -> CB), prologue bn0+mish applied while staging; slice 1 is
+    // fetched into registers under the slice-0 MFMAs ------------------------------------
     acc_zero<G, CB>(acc);
-#pragma unroll 1
-    for (int ip = 0; ip < C / CB; ++ip) {
-      if (ip > 0) lds_barrier();
-      stage_in<G, true>(smem, a.x, C, pos0, a.npos, ip * G::NCH, a.scale[0], a.shift[0]);
-      conv_segment<G, CB, 1, 1>(ring, smem, acc);
-    }
+    stage_store<G, true>(smem, xr, 0, a.scale[0], a.shift[0]);
+    stage_load<G>(xr, a.x, C, pos0, a.npos, G::NCH);
+    ring_note_xloads(ring);
+    P3_STAMP(1);
+    conv_segment<G, CB, 1, 1, STAMPS>(ring, smem, acc);
+    P3_STAMP(2);
+    lds_barrier();
+    stage_store<G, true>(smem, xr, G::NCH, a.scale[0], a.shift[0]);
+    P3_STAMP(3);
+    conv_segment<G, CB, 1, 1, STAMPS>(ring, smem, acc);
+    P3_STAMP(4);
     if (KIND == 0) {
 #pragma unroll 1
       for (int j = 1; j <= L; ++j) {
         lds_barrier();
         epilogue_to_act<G, CB>(smem, acc, a.scale[j], a.shift[j], 0);
         acc_zero<G, CB>(acc);
-        conv_segment<G, CB, 3, 9>(ring, smem, acc);
+        P3_STAMP(3 + 2 * j);
+        conv_segment<G, CB, 3, 9, STAMPS>(ring, smem, acc);
+        P3_STAMP(4 + 2 * j);
+        if (STAMPS && (threadIdx.x & 63) == 0 && npos_done < 4) {
+          const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+          if (w_ == 0 || w_ == 7) a.stamps[((blockIdx.x * 2 + (w_ == 7)) * 4 + npos_done) * 32 + 20 + j] = ring.wait_cycles;
+        }
       }
       lds_barrier();
       epilogue_to_act<G, CB>(smem, acc, a.scale[L + 1], a.shift[L + 1], 0);
+      P3_STAMP(11);
     } else {
       // nbt: keep the raw inner residual t in registers (fp32, same tile as acc)
       f32x16 t[2][T::NT];
@@ -69,11 +97,11 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
         lds_barrier();
         epilogue_to_act<G, CB>(smem, t, a.scale[1 + 2 * r], a.shift[1 + 2 * r], 0);
         acc_zero<G, CB>(acc);
-        conv_segment<G, CB, 3, 9>(ring, smem, acc);
+        conv_segment<G, CB, 3, 9, STAMPS>(ring, smem, acc);
         lds_barrier();
         epilogue_to_act<G, CB>(smem, acc, a.scale[2 + 2 * r], a.shift[2 + 2 * r], 0);
         acc_zero<G, CB>(acc);
-        conv_segment<G, CB, 3, 9>(ring, smem, acc);
+        conv_segment<G, CB, 3, 9, STAMPS>(ring, smem, acc);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -82,14 +110,21 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
       lds_barrier();
       epilogue_to_act<G, CB>(smem, t, a.scale[5], a.shift[5], 0);
     }
-    // ---- expand 1x1 (CB -> C) + residual, straight to HBM ---------------------------
+    // ---- expand 1x1 (CB -> C) + residual, straight to HBM; the next position's first
+    // slice is fetched into registers under it ------------------------------------------
+    stage_load<G>(xr, a.x, C, pos0 + gridDim.x * NPOS, a.npos, 0);
+    ring_note_xloads(ring);
+    P3_STAMP(12);
 #pragma unroll 1
     for (int cp = 0; cp < C / CB; ++cp) {
       acc_zero<G, CB>(acc);
-      conv_segment<G, CB, 1, 1>(ring, smem, acc);
+      conv_segment<G, CB, 1, 1, STAMPS>(ring, smem, acc);
+      P3_STAMP(13 + 2 * cp);
       epilogue_to_global<G, CB, true>(acc, a.x, C, pos0, a.npos, cp * CB);
+      P3_STAMP(14 + 2 * cp);
     }
     lds_barrier();
+    P3_STAMP(17);
   }
   ring_drain();
 }
@@ -113,7 +148,7 @@ __global__ void __launch_bounds__(kWG, 2) k_init(InitArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr uint32_t kRingOff = G::ACT_BYTES;
   act_zero<G>(smem);
-  Ring ring;
+  Ring<T::RS> ring;
   ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
   lds_barrier();
   const int lane = threadIdx.x & 63;
@@ -164,7 +199,7 @@ __global__ void __launch_bounds__(kWG, 2) k_init(InitArgs a) {
     for (int cp = 0; cp < C / CP; ++cp) {
       f32x16 acc[2][T::NT];
       acc_zero<G, CP>(acc);
-      conv_segment<G, CP, 5, 26>(ring, smem, acc);
+      conv_segment<G, CP, 5, 28>(ring, smem, acc);
       // epilogue: + (gs . Wg + b)[c]  -> x
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -218,7 +253,7 @@ __global__ void __launch_bounds__(kWG, 2) k_conv1x1(Conv1x1Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr uint32_t kRingOff = G::ACT_BYTES;
   act_zero<G>(smem);
-  Ring ring;
+  Ring<T::RS> ring;
   ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
   lds_barrier();
   const int lane = threadIdx.x & 63;
@@ -290,7 +325,7 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
   constexpr uint32_t kRingOff = kTtBytes;
   constexpr int NQ = 24;                        // k16 steps over i (384)
   for (int i = threadIdx.x * 16; i < (int)kTtBytes; i += kWG * 16) *(f32x4*)(smem + i) = f32x4{0, 0, 0, 0};
-  Ring ring;
+  Ring<16384> ring;
   ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
   lds_barrier();
   const int lane = threadIdx.x & 63;
@@ -318,10 +353,10 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
         const uint32_t b_off = (uint32_t)((h * 128 + jg * 64 + lr) * 16);
         const uint32_t a_base = (uint32_t)((ct * 32 + lr) * kTtStride + h * 16);
         uint32_t wslot = 0;
-#pragma unroll 2
+#pragma unroll 4
         for (int q = 0; q < NQ; ++q) {
-          if ((q & 1) == 0) wslot = ring_acquire(ring, smem);
-          const uint32_t wk = wslot + (q & 1) * 4096;
+          if ((q & 3) == 0) wslot = ring_acquire(ring, smem);
+          const uint32_t wk = wslot + (q & 3) * 4096;
           const h8 av = *(const h8*)(smem + a_base + q * 32);
           const h8 b0 = *(const h8*)(smem + wk + b_off);
           const h8 b1 = *(const h8*)(smem + wk + b_off + 512);
@@ -517,7 +552,7 @@ __global__ void __launch_bounds__(256) k_heads(HeadsArgs a) {
 template <int C, int CB, int KIND, int L>
 static hipError_t launch_block_t(const BlockArgs& a, int grid, hipStream_t s) {
   using G = Geo<128 / CB, CB, 3>;
-  constexpr size_t lds = G::ACT_BYTES + kRingBytes;
+  constexpr size_t lds = G::ACT_BYTES + ring_bytes(CB);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_block<C, CB, KIND, L>,
@@ -526,6 +561,16 @@ static hipError_t launch_block_t(const BlockArgs& a, int grid, hipStream_t s) {
     attr_set = true;
   }
   hipLaunchKernelGGL((k_block<C, CB, KIND, L>), dim3(grid), dim3(kWG), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_block_stamps(const BlockArgs& a, int grid, hipStream_t s) {
+  using G = Geo<1, 128, 3>;
+  constexpr size_t lds = G::ACT_BYTES + ring_bytes(128);
+  hipError_t e = hipFuncSetAttribute((const void*)k_block<256, 128, 0, 3, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_block<256, 128, 0, 3, true>), dim3(grid), dim3(kWG), lds, s, a);
   return hipGetLastError();
 }
 
@@ -548,7 +593,7 @@ static hipError_t set_lds(K kernel, size_t lds) {
 
 hipError_t launch_init(int C, const InitArgs& a, int grid, hipStream_t s) {
   using G = Geo<1, 16, 5>;
-  constexpr size_t lds = G::ACT_BYTES + kRingBytes;
+  constexpr size_t lds = G::ACT_BYTES + ring_bytes(128);
   if (C == 256) {
     hipLaunchKernelGGL((k_init<256>), dim3(grid), dim3(kWG), lds, s, a);
   } else if (C == 128) {
@@ -563,7 +608,8 @@ template <int CIN, int COUT, bool PRE, int EPI>
 static hipError_t launch_conv1x1_t(const Conv1x1Args& a, int grid, hipStream_t s) {
   constexpr int CB = CIN >= 256 ? 128 : 64;
   using G = Geo<128 / CB, CB, 1>;
-  constexpr size_t lds = G::ACT_BYTES + kRingBytes;
+  constexpr int CP = (COUT >= 128 && CB == 128) ? 128 : 64;
+  constexpr size_t lds = G::ACT_BYTES + ring_bytes(CP);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = set_lds(k_conv1x1<CIN, COUT, PRE, EPI>, lds);
@@ -588,7 +634,7 @@ hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipS
 }
 
 hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s) {
-  constexpr size_t lds = 128 * kTtStride + kRingBytes;
+  constexpr size_t lds = 128 * kTtStride + ring_bytes(128);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = set_lds(k_bdense<256>, lds);

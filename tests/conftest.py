@@ -1,0 +1,48 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Builds libp3hip.so / liboracle.so in-tree if they are missing (cross-compiles on CPU)."""
+    import __graft_entry__ as g
+    from p3achygo_amd import engine
+    if not os.path.exists(engine.LIB_PATH) or not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        g.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def weight_files(tmp_path_factory):
+    """name -> path of a seeded random-init .p3w (randomised BN stats), generated on demand."""
+    from p3achygo_amd import netspec
+    d = tmp_path_factory.mktemp("weights")
+    cache = {}
+
+    def get(name, randomize=True):
+        key = (name, randomize)
+        if key not in cache:
+            cfg = netspec.CONFIGS[name]
+            p = os.path.join(d, f"{name}_{int(randomize)}.p3w")
+            netspec.save_p3w(p, cfg, netspec.generate_weights(cfg, randomize=randomize))
+            cache[key] = p
+        return cache[key]
+    return get
+
+
+def load_golden(name):
+    import numpy as np
+    from p3achygo_amd import features
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"nn_{name}.npz"))
+    pos = np.frombuffer(g["features"].tobytes(), dtype=features.features_dtype()).copy()
+    return g, pos

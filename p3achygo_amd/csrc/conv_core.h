@@ -60,6 +60,14 @@ struct Geo {
   static constexpr int NT_TOTAL = NPOS * NT_POS;
 };
 
+// Returns v unchanged but opaque to the optimiser: address arithmetic derived from it is
+// recomputed where it is used instead of being hoisted out of the position loop and
+// spilled to scratch (a handful of VALU ops vs a scratch round trip per use).
+__device__ __forceinline__ int launder(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 template <int NCH>
 __device__ __forceinline__ int swz(int slot) {
   static_assert(NCH == 2 || NCH == 4 || NCH == 8 || NCH == 16, "NCH");
@@ -76,11 +84,12 @@ __device__ __forceinline__ bool row_valid(int r, int& loc) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Fast mish: x * tanh(softplus(x)) = x * w / (w + 2), w = e^x (e^x + 2).
+// Fast mish: x * tanh(softplus(x)) = x * (1 - 2 / (s*s + 1)),  s = e^x + 1.
+// No clamp needed: e^x -> inf gives s*s+1 = inf, rcp = 0, result x; e^x -> 0 gives 0.
 __device__ __forceinline__ float mish_f(float x) {
-  float e = __builtin_amdgcn_exp2f(fminf(x, 20.0f) * 1.4426950408889634f);
-  float w = e * (e + 2.0f);
-  return x * w * __builtin_amdgcn_rcpf(w + 2.0f);
+  const float s = __builtin_amdgcn_exp2f(x * 1.4426950408889634f) + 1.0f;
+  const float r = __builtin_amdgcn_rcpf(__builtin_fmaf(s, s, 1.0f));
+  return __builtin_fmaf(-2.0f * x, r, x);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -96,7 +105,8 @@ struct Ring {
   int pf;              // next stream macro-step to prefetch (circular)
   int pf_slot;
   int slot;            // ring slot of the next macro-step to consume
-  int tol;             // acquires left that must tolerate kXLoads younger register loads
+  int tol;             // acquires left that must tolerate `extra` younger register loads/stores
+  int extra;           // 12, 24 or 48 (see ring_note_inflight)
   unsigned long long wait_cycles;  // diagnostic builds: cycles spent in ring_acquire waits
 };
 
@@ -128,6 +138,7 @@ __device__ __forceinline__ void ring_init(Ring<RS>& r, char* smem, const void* g
   r.pf_slot = 0;
   r.slot = 0;
   r.tol = 0;
+  r.extra = 0;
   r.wait_cycles = 0;
   for (int i = 0; i < kRingDepth; ++i) ring_issue(r, smem);
 }
@@ -150,12 +161,21 @@ __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
   static_assert(kRingDepth == 2 && kXLoads == 12, "vmcnt immediates below");
   unsigned long long t0 = 0;
   if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
+  constexpr int G = Ring<RS>::G;  // base immediate (D-1)*G = G
   if (r.tol > 0) {
-    if (Ring<RS>::G == 2) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory");
     r.tol--;
+    if (r.extra == 12) {
+      if (G == 2) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory");
+    } else if (r.extra == 24) {
+      if (G == 2) asm volatile("s_waitcnt vmcnt(26) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(25) lgkmcnt(0)" ::: "memory");
+    } else {
+      if (G == 2) asm volatile("s_waitcnt vmcnt(50) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(49) lgkmcnt(0)" ::: "memory");
+    }
   } else {
-    if (Ring<RS>::G == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    if (G == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
@@ -167,10 +187,16 @@ __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
   return off;
 }
 
-// Call right after issuing the kXLoads prefetch loads (and nothing else since the last
-// ring_issue).
+// Call right after issuing `extra` (12, 24 or 48) ordinary vector-memory operations whose
+// completion should not be forced by the next D ring acquires (and nothing else since the
+// last ring_issue): the glds those acquires wait for are older than all of them.
 template <int RS>
-__device__ __forceinline__ void ring_note_xloads(Ring<RS>& r) { r.tol = kRingDepth; }
+__device__ __forceinline__ void ring_note_inflight(Ring<RS>& r, int extra) {
+  r.tol = kRingDepth;
+  r.extra = extra;
+}
+template <int RS>
+__device__ __forceinline__ void ring_note_xloads(Ring<RS>& r) { ring_note_inflight(r, kXLoads); }
 
 __device__ __forceinline__ void ring_drain() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -305,6 +331,12 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][NTn]) {
       for (int i = 0; i < 16; ++i) acc[mt][j][i] = 0.0f;
 }
 
+template <class G, int COUT_PASS>
+__device__ __forceinline__ int cg_of() {
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  return wid % Tiling<G, COUT_PASS>::CG;
+}
+
 // Channel (within the pass) of accumulator register quad g4 (0..3) of cout tile mt.
 template <class G, int COUT_PASS>
 __device__ __forceinline__ int acc_chan(int mt, int g4) {
@@ -323,7 +355,7 @@ __device__ __forceinline__ void epilogue_to_act(char* smem, f32x16 (&acc)[2][NTn
                                                 const float* __restrict__ scale,
                                                 const float* __restrict__ shift, int cofs) {
   using T = Tiling<G, COUT_PASS>;
-  const int lane = threadIdx.x & 63;
+  const int lane = launder(threadIdx.x & 63);
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lg = wid / T::CG;
   const int lr = lane & 31, h = lane >> 5;
@@ -367,7 +399,8 @@ template <class G>
 __device__ __forceinline__ void stage_load(XRegs<G>& xr, const _Float16* __restrict__ x, int C,
                                            int pos0, int npos, int cblk0) {
   static_assert(G::NPOS * G::NCH == 16 && kXLoads * 32 >= kNLoc, "staging map");
-  const int combo = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+  const int tid = launder(threadIdx.x);
+  const int combo = tid >> 5, l32 = tid & 31;
   const int p = combo / G::NCH, kc = combo - p * G::NCH;
   int pos = pos0 + p;
   if (pos >= npos) pos = npos - 1;
@@ -384,7 +417,8 @@ template <class G, bool PRE>
 __device__ __forceinline__ void stage_store(char* smem, const XRegs<G>& xr, int cblk0,
                                             const float* __restrict__ scale,
                                             const float* __restrict__ shift) {
-  const int combo = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+  const int tid = launder(threadIdx.x);
+  const int combo = tid >> 5, l32 = tid & 31;
   const int p = combo / G::NCH, kc = combo - p * G::NCH;
   f32x4 s0, s1, t0, t1;
   if (PRE) {
@@ -412,6 +446,7 @@ __device__ __forceinline__ void stage_store(char* smem, const XRegs<G>& xr, int 
     const int sl = p * G::PSLOTS + G::PADTOP + y * G::S + xx;
     const int ch = kc ^ swz<G::NCH>(sl);
     *(h8*)(smem + sl * G::SLOTB + ch * 16) = o;
+    if (i & 1) __builtin_amdgcn_sched_barrier(0);  // bound the live range: 2 items in flight
   }
 }
 
@@ -430,39 +465,54 @@ __device__ __forceinline__ void act_zero(char* smem) {
   for (int i = threadIdx.x * 16; i < G::ACT_BYTES; i += kWG * 16) *(f32x4*)(smem + i) = f32x4{0, 0, 0, 0};
 }
 
-// Epilogue B: out[c][loc] = acc (+ residual read from the same place) -> fp16 global, in
-// the channel-blocked layout.  cofs = first channel of this cout pass.  All residual
-// loads are issued before the first store (loads and stores go through the same pointer,
-// so the compiler would otherwise serialise load -> store -> load on possible aliasing).
-template <class G, int COUT_PASS, bool RESIDUAL, int NTn>
-__device__ __forceinline__ void epilogue_to_global(f32x16 (&acc)[2][NTn],
-                                                   _Float16* __restrict__ x, int C, int pos0,
-                                                   int npos, int cofs) {
+// Epilogue B: out[c][loc] = acc + residual (read from the same place) -> fp16 global, in
+// the channel-blocked layout; cofs = first channel of this cout pass.  Split in two so the
+// 24 residual loads can be issued before the conv segment whose result they are added to
+// (their latency hides under its MFMAs): residual_load, then epilogue_residual_store.
+template <class G, int COUT_PASS, int NTn>
+struct ResRegs {
+  h4 rv[NTn][8];
+  size_t base[NTn];
+  bool ok[NTn];
+};
+
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void residual_addr(ResRegs<G, COUT_PASS, NTn>& rr, int C, int pos0,
+                                              int npos, int cofs) {
   using T = Tiling<G, COUT_PASS>;
-  const int lane = threadIdx.x & 63;
+  const int lane = launder(threadIdx.x & 63);
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lg = wid / T::CG;
   const int lr = lane & 31, h = lane >> 5;
-  const int c0 = cofs + acc_chan<G, COUT_PASS>(0, 0);   // channel of (mt=0, g4=0)
-  size_t base[NTn];
-  bool ok[NTn];
+  const int c0 = cofs + cg_of<G, COUT_PASS>() * 64 + h * 4;   // channel of (mt=0, g4=0)
 #pragma unroll
   for (int j = 0; j < NTn; ++j) {
     const int t = lg + j * T::LG;
     const int tv = t < G::NT_TOTAL ? t : lg;
     const int p = tv / G::NT_POS, tt = tv - p * G::NT_POS;
     int loc;
-    ok[j] = row_valid<G::S>(tt * 32 + lr, loc) && (pos0 + p < npos) && (t < G::NT_TOTAL);
-    base[j] = ((size_t)(pos0 + p) * (C / 8) + (c0 >> 3)) * (kNLoc * 8) + loc * 8 + h * 4;
+    rr.ok[j] = row_valid<G::S>(tt * 32 + lr, loc) && (pos0 + p < npos) && (t < G::NT_TOTAL);
+    if (!rr.ok[j]) loc = 0;
+    const int pp = (pos0 + p < npos) ? pos0 + p : npos - 1;
+    rr.base[j] = ((size_t)pp * (C / 8) + (c0 >> 3)) * (kNLoc * 8) + loc * 8 + h * 4;
   }
-  h4 rv[NTn][8];
-  if (RESIDUAL) {
+}
+
+// Issues exactly NTn*8 = 24 loads per lane (invalid rows read a valid dummy address).
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void residual_load(ResRegs<G, COUT_PASS, NTn>& rr,
+                                              const _Float16* __restrict__ x) {
 #pragma unroll
-    for (int j = 0; j < NTn; ++j)
+  for (int j = 0; j < NTn; ++j)
 #pragma unroll
-      for (int k = 0; k < 8; ++k)   // k = mt*4 + g4: channel block c0/8 + k
-        if (ok[j]) rv[j][k] = *(const h4*)(x + base[j] + (size_t)k * (kNLoc * 8));
-  }
+    for (int k = 0; k < 8; ++k)   // k = mt*4 + g4: channel block c0/8 + k
+      rr.rv[j][k] = *(const h4*)(x + rr.base[j] + (size_t)k * (kNLoc * 8));
+}
+
+template <class G, int COUT_PASS, bool RESIDUAL, int NTn>
+__device__ __forceinline__ void epilogue_store(f32x16 (&acc)[2][NTn],
+                                               const ResRegs<G, COUT_PASS, NTn>& rr,
+                                               _Float16* __restrict__ x) {
 #pragma unroll
   for (int j = 0; j < NTn; ++j)
 #pragma unroll
@@ -472,11 +522,21 @@ __device__ __forceinline__ void epilogue_to_global(f32x16 (&acc)[2][NTn],
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float v = acc[mt][j][g4 * 4 + i];
-        if (RESIDUAL) v += (float)rv[j][k][i];
+        if (RESIDUAL) v += (float)rr.rv[j][k][i];
         o[i] = (_Float16)v;
       }
-      if (ok[j]) *(h4*)(x + base[j] + (size_t)k * (kNLoc * 8)) = o;
+      if (rr.ok[j]) *(h4*)(x + rr.base[j] + (size_t)k * (kNLoc * 8)) = o;
     }
+}
+
+template <class G, int COUT_PASS, bool RESIDUAL, int NTn>
+__device__ __forceinline__ void epilogue_to_global(f32x16 (&acc)[2][NTn],
+                                                   _Float16* __restrict__ x, int C, int pos0,
+                                                   int npos, int cofs) {
+  ResRegs<G, COUT_PASS, NTn> rr;
+  residual_addr<G, COUT_PASS, NTn>(rr, C, pos0, npos, cofs);
+  if (RESIDUAL) residual_load<G, COUT_PASS, NTn>(rr, x);
+  epilogue_store<G, COUT_PASS, RESIDUAL, NTn>(acc, rr, x);
 }
 
 }  // namespace p3

@@ -56,8 +56,8 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
     P3_STAMP(0);
     // ---- reduce 1x1 (C -> CB), prologue bn0+mish applied while staging; slice 1 is
     // fetched into registers under the slice-0 MFMAs ------------------------------------
-    acc_zero<G, CB>(acc);
     stage_store<G, true>(smem, xr, 0, a.scale[0], a.shift[0]);
+    acc_zero<G, CB>(acc);
     stage_load<G>(xr, a.x, C, pos0, a.npos, G::NCH);
     ring_note_xloads(ring);
     P3_STAMP(1);
@@ -68,6 +68,8 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
     P3_STAMP(3);
     conv_segment<G, CB, 1, 1, STAMPS>(ring, smem, acc);
     P3_STAMP(4);
+    // The next position's first slice is fetched into registers under the last 3x3 conv.
+    const int pos_next = pos0 + gridDim.x * NPOS;
     if (KIND == 0) {
 #pragma unroll 1
       for (int j = 1; j <= L; ++j) {
@@ -75,6 +77,10 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
         epilogue_to_act<G, CB>(smem, acc, a.scale[j], a.shift[j], 0);
         acc_zero<G, CB>(acc);
         P3_STAMP(3 + 2 * j);
+        if (j == L) {
+          stage_load<G>(xr, a.x, C, pos_next, a.npos, 0);
+          ring_note_xloads(ring);
+        }
         conv_segment<G, CB, 3, 9, STAMPS>(ring, smem, acc);
         P3_STAMP(4 + 2 * j);
         if (STAMPS && (threadIdx.x & 63) == 0 && npos_done < 4) {
@@ -109,18 +115,23 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
       }
       lds_barrier();
       epilogue_to_act<G, CB>(smem, t, a.scale[5], a.shift[5], 0);
+      stage_load<G>(xr, a.x, C, pos_next, a.npos, 0);
+      ring_note_xloads(ring);
     }
-    // ---- expand 1x1 (CB -> C) + residual, straight to HBM; the next position's first
-    // slice is fetched into registers under it ------------------------------------------
-    stage_load<G>(xr, a.x, C, pos0 + gridDim.x * NPOS, a.npos, 0);
-    ring_note_xloads(ring);
+    // ---- expand 1x1 (CB -> C) + residual, straight to HBM.  The residual of each output
+    // pass is loaded before that pass's MFMAs (24 loads/lane); in pass 1 the 24 stores of
+    // pass 0 are in flight as well ------------------------------------------------------
     P3_STAMP(12);
 #pragma unroll 1
     for (int cp = 0; cp < C / CB; ++cp) {
+      ResRegs<G, CB, T::NT> rr;
+      residual_addr<G, CB, T::NT>(rr, C, pos0, a.npos, cp * CB);
+      residual_load<G, CB, T::NT>(rr, a.x);
+      if (KIND == 0) ring_note_inflight(ring, cp == 0 ? 24 : 48);
       acc_zero<G, CB>(acc);
       conv_segment<G, CB, 1, 1, STAMPS>(ring, smem, acc);
       P3_STAMP(13 + 2 * cp);
-      epilogue_to_global<G, CB, true>(acc, a.x, C, pos0, a.npos, cp * CB);
+      epilogue_store<G, CB, true, T::NT>(acc, rr, a.x);
       P3_STAMP(14 + 2 * cp);
     }
     lds_barrier();

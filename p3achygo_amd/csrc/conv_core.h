@@ -4,8 +4,8 @@
 // owns NPOS whole 19x19 positions.  The activated input of the current conv layer lives
 // in LDS ("act buffer"): one slot of NCH 16-byte chunks (8 fp16 channels each) per board
 // point, laid out on a column-padded grid (row stride S = 19 + pad) with zero pad slots,
-// so a KxK tap is a constant slot shift and needs no bounds checks.  Chunks are
-// XOR-swizzled by slot so that ds_read_b128 fragment reads are bank-conflict free.
+// so a KxK tap is a constant slot shift and needs no bounds checks.  Slots are
+// padded by 16 bytes so that ds_read_b128 fragment reads are bank-conflict free.
 //
 // Convolutions are implicit GEMMs on v_mfma_f32_32x32x16_f16 in the orientation
 //   D'[cout][loc] = sum_k W[cout][k] * act[k][loc]
@@ -49,14 +49,21 @@ struct Geo {
   static constexpr int NPOS = NPOS_;
   static constexpr int CB = CB_;                 // channels resident in the act buffer
   static constexpr int NCH = CB / 8;             // 16-byte chunks per slot
-  static constexpr int SLOTB = CB * 2;           // bytes per slot
+  // bytes per slot: the channels plus one 16-byte pad.  The slot stride is then an odd
+  // number of 16-byte bank groups (17, 9 or 3), so 16 consecutive slots read at the same
+  // chunk hit 16 distinct bank groups: ds_read_b128 fragment reads are conflict-free with
+  // plain (base + immediate) addressing, no swizzle arithmetic in the K loop.
+  static constexpr int SLOTB = CB * 2 + 16;
   static constexpr int PAD = KW_ / 2;
   static constexpr int S = kBL + PAD;            // padded row stride
   static constexpr int NROWS = (kBL - 1) * S + kBL;             // last valid row + 1
   static constexpr int NT_POS = (NROWS + 31) / 32;              // location tiles per position
   static constexpr int PADTOP = PAD * S + PAD;                  // slots above row 0
-  static constexpr int PSLOTS = PADTOP + NT_POS * 32 + PADTOP;  // slots per position
-  static constexpr int ACT_BYTES = NPOS * PSLOTS * SLOTB;
+  // slots per position.  Rows >= NROWS of the last location tile are never valid; their
+  // (discarded) fragment reads run a few slots past this position into the next one or
+  // into the ring, which always follows the act buffer in the same LDS allocation.
+  static constexpr int PSLOTS = PADTOP + NROWS + PADTOP;
+  static constexpr int ACT_BYTES = (NPOS * PSLOTS * SLOTB + 15) / 16 * 16;
   static constexpr int NT_TOTAL = NPOS * NT_POS;
 };
 
@@ -68,11 +75,6 @@ __device__ __forceinline__ int launder(int v) {
   return v;
 }
 
-template <int NCH>
-__device__ __forceinline__ int swz(int slot) {
-  static_assert(NCH == 2 || NCH == 4 || NCH == 8 || NCH == 16, "NCH");
-  return (slot / (16 / NCH)) & (NCH - 1);
-}
 
 // row (column-padded index) -> validity and plain location
 template <int S>
@@ -108,6 +110,7 @@ struct Ring {
   int tol;             // acquires left that must tolerate `extra` younger register loads/stores
   int extra;           // 12, 24 or 48 (see ring_note_inflight)
   unsigned long long wait_cycles;  // diagnostic builds: cycles spent in ring_acquire waits
+  int dbg;             // diagnostic builds: bit0 = skip waits/barriers/prefetch (timing only)
 };
 
 // Register prefetch of the next activation slice: every thread issues exactly kXLoads
@@ -140,6 +143,7 @@ __device__ __forceinline__ void ring_init(Ring<RS>& r, char* smem, const void* g
   r.tol = 0;
   r.extra = 0;
   r.wait_cycles = 0;
+  r.dbg = 0;
   for (int i = 0; i < kRingDepth; ++i) ring_issue(r, smem);
 }
 
@@ -160,7 +164,14 @@ template <bool STAMPS = false, int RS = 0>
 __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
   static_assert(kRingDepth == 2 && kXLoads == 12, "vmcnt immediates below");
   unsigned long long t0 = 0;
-  if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
+  if (STAMPS) {
+    if (r.dbg & 1) {  // timing experiment: no synchronisation at all (results are garbage)
+      uint32_t off = r.lds_base + r.slot * RS;
+      r.slot = (r.slot + 1 == kRingSlots) ? 0 : r.slot + 1;
+      return off;
+    }
+    t0 = __builtin_amdgcn_s_memtime();
+  }
   constexpr int G = Ring<RS>::G;  // base immediate (D-1)*G = G
   if (r.tol > 0) {
     r.tol--;
@@ -230,12 +241,32 @@ __device__ __forceinline__ int tile_slot0(int t) {
   return p * G::PSLOTS + G::PADTOP + tt * 32;
 }
 
+// 16-byte LDS read hidden from hipcc's waitcnt bookkeeping (cdna_hip_programming.md §5.7
+// form (iii)): the caller counts lgkmcnt itself and fences consumers with sched_barrier.
+template <int OFF>
+__device__ __forceinline__ h8 lds_read128(uint32_t addr) {
+  h8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // One conv segment: acc[mt][j] += W_seg x act over NK16 k16-steps taken in the order
 // (tap major, channel-chunk-pair minor).  KW = kernel width (1, 3 or 5); NTAPS_PAD is the
 // number of taps in the packed stream (>= KW*KW, zero weights beyond).
-// Loop shape: a runtime outer loop whose body is U = max(NQ, KMS) fully unrolled k16-steps,
-// fragments double-buffered by the (static) parity of the step, next step's fragments
-// (and, every KMS steps, the next ring slot) fetched before the current step's MFMAs.
+//
+// Schedule: every wave's instruction stream must be MFMA-dense on its own, because the two
+// waves of a SIMD share one matrix pipe and the older wave wins every arbitration (a wave
+// that stalls on LDS leaves the pipe idle while its partner is blocked behind its own
+// in-order MFMAs).  Fragments are therefore fetched TWO k16-steps ahead into a 3-deep
+// register ring with hand-issued ds_read_b128, and each MFMA burst waits with a counted
+// lgkmcnt for exactly its own fragments (the 2+NT reads of the following step stay in
+// flight).  Body = U fully unrolled steps (U % 3 == 0 or the whole segment), runtime outer
+// loop; a new ring slot is acquired whenever the step being FETCHED enters a macro-step.
 template <class G, int COUT_PASS, int KW, int NTAPS_PAD, bool STAMPS = false, int NTn = 0>
 __device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS)>& ring, char* smem,
                                              f32x16 (&acc)[2][NTn]) {
@@ -243,10 +274,11 @@ __device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS)>& r
   static_assert(NTn == T::NT, "accumulator shape");
   constexpr int NQ = G::CB / 16;                 // k16-steps per tap
   constexpr int NK16 = NTAPS_PAD * NQ;
-  constexpr int U = NQ > T::KMS ? NQ : T::KMS;   // unrolled body length
+  constexpr int U = (NK16 <= 28) ? NK16 : 3 * NQ;  // unrolled body length
   constexpr int NOUT = NK16 / U;
-  constexpr int TPB = U / NQ;                    // taps per body (>1 only when NQ < KMS)
-  static_assert(NK16 % U == 0 && U % T::KMS == 0 && U % NQ == 0 && U % 2 == 0, "segment shape");
+  constexpr int NLD = 2 + T::NT;                 // LDS reads per step
+  static_assert(NK16 % U == 0 && U % T::KMS == 0 && (NOUT == 1 || (U % 3 == 0 && U % NQ == 0)) &&
+                NK16 >= 3, "segment shape");
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cg = wid % T::CG, lg = wid / T::CG;
@@ -261,63 +293,87 @@ __device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS)>& r
   }
   // A fragment offset inside a k16 block: [h][cout][8] fp16
   const uint32_t a_off = (uint32_t)((h * COUT_PASS + cg * 64 + lr) * 16);
+  uint32_t a_addr = 0;       // LDS byte address of this lane's A fragment in the current slot
+  uint32_t b_base[T::NT];    // per-tap: byte address of the shifted slot (+ lane half)
+  h8 fa[3][2], fb[3][T::NT];
 
-  // per-tap B addressing: byte base of the shifted slot and its swizzle
-  struct TapAddr { uint32_t base[T::NT]; int sw[T::NT]; };
-  auto tap_addr = [&](int tap, TapAddr& ta) {
-    int shift = 0;
-    if (KW > 1) {
-      const int ky = tap / KW, kx = tap - ky * KW;
-      shift = (tap < KW * KW) ? (ky - KW / 2) * G::S + (kx - KW / 2) : 0;
-    }
+  // Issues piece `pc` of the LDS reads of step v of body o (v is static; v may run past U
+  // into the next body, the caller guarantees the step exists).  Piece 0 = ring slot /
+  // tap addressing + the two A reads, piece 1+j = B read of location tile j.  The pieces
+  // are interleaved one per MFMA so that their issue hides in the MFMA shadows.
+  auto fetch_piece = [&](int o, int v, int pc) {
+    const int vv = v % U;                      // static step inside its body
+    const int ob = o + v / U;                  // runtime body index
+    const int q = vv % NQ;
+    const int buf = v % 3;                     // == (global step) % 3 since U % 3 == 0 or NOUT == 1
+    constexpr int KB = COUT_PASS * 32;         // bytes per k16 block
+    const int kk = vv % T::KMS;
+    if (pc == 0) {
+      if (kk == 0) a_addr = ring_acquire<STAMPS>(ring, smem) + a_off;
+      if (vv % NQ == 0) {
+        const int tap = ob * (U / NQ) + vv / NQ;
+        int shift = 0;
+        if (KW > 1) {
+          const int ky = tap / KW, kx = tap - ky * KW;
+          shift = (tap < KW * KW) ? (ky - KW / 2) * G::S + (kx - KW / 2) : 0;
+        }
 #pragma unroll
-    for (int j = 0; j < T::NT; ++j) {
-      const int sl = slot0[j] + shift;
-      ta.base[j] = (uint32_t)(sl * G::SLOTB);
-      ta.sw[j] = swz<G::NCH>(sl);
-    }
-  };
-  h8 fa[2][2], fb[2][T::NT];
-  uint32_t wslot = 0;
-  // u = static step index inside the body; q = u % NQ is static too
-  auto load_frags = [&](const TapAddr& ta, int u, int buf) {
-    const int q = u % NQ;
-    const uint32_t wk = wslot + (uint32_t)((u % T::KMS) * (COUT_PASS * 32));
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) fa[buf][mt] = *(const h8*)(smem + wk + a_off + mt * 512);
-#pragma unroll
-    for (int j = 0; j < T::NT; ++j)
-      fb[buf][j] = *(const h8*)(smem + ta.base[j] + (((2 * q + h) ^ ta.sw[j]) << 4));
-  };
-
-  TapAddr cur[TPB], nxt[TPB];
-#pragma unroll
-  for (int t = 0; t < TPB; ++t) tap_addr(t, cur[t]);
-  wslot = ring_acquire<STAMPS>(ring, smem);
-  load_frags(cur[0], 0, 0);
-#pragma unroll 1
-  for (int o = 0; o < NOUT; ++o) {
-    if (o + 1 < NOUT) {
-#pragma unroll
-      for (int t = 0; t < TPB; ++t) tap_addr((o + 1) * TPB + t, nxt[t]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (u + 1 < U) {
-        if (((u + 1) % T::KMS) == 0) wslot = ring_acquire<STAMPS>(ring, smem);
-        load_frags(cur[(u + 1) / NQ], u + 1, (u + 1) & 1);
-      } else if (o + 1 < NOUT) {
-        wslot = ring_acquire<STAMPS>(ring, smem);
-        load_frags(nxt[0], 0, 0);
+        for (int j = 0; j < T::NT; ++j) {
+          const int sl = slot0[j] + shift;
+          b_base[j] = (uint32_t)(sl * G::SLOTB + h * 16);
+        }
       }
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int j = 0; j < T::NT; ++j)
-          acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u & 1][mt], fb[u & 1][j], acc[mt][j], 0, 0, 0);
+      for (int mt = 0; mt < 2; ++mt) {
+        // offset immediate must be a literal: dispatch on the (static) k16 index in the slot
+        if (kk == 0) fa[buf][mt] = mt ? lds_read128<512>(a_addr) : lds_read128<0>(a_addr);
+        else if (kk == 1) fa[buf][mt] = mt ? lds_read128<KB + 512>(a_addr) : lds_read128<KB>(a_addr);
+        else if (kk == 2) fa[buf][mt] = mt ? lds_read128<2 * KB + 512>(a_addr) : lds_read128<2 * KB>(a_addr);
+        else fa[buf][mt] = mt ? lds_read128<3 * KB + 512>(a_addr) : lds_read128<3 * KB>(a_addr);
+      }
+    } else {
+      const int j = pc - 1;
+      // chunk 2q+h of the slot: the k16 index q is static, so it is an immediate offset
+      switch (q) {
+        case 0: fb[buf][j] = lds_read128<0>(b_base[j]); break;
+        case 1: fb[buf][j] = lds_read128<32>(b_base[j]); break;
+        case 2: fb[buf][j] = lds_read128<64>(b_base[j]); break;
+        case 3: fb[buf][j] = lds_read128<96>(b_base[j]); break;
+        case 4: fb[buf][j] = lds_read128<128>(b_base[j]); break;
+        case 5: fb[buf][j] = lds_read128<160>(b_base[j]); break;
+        case 6: fb[buf][j] = lds_read128<192>(b_base[j]); break;
+        default: fb[buf][j] = lds_read128<224>(b_base[j]); break;
+      }
     }
+  };
+  auto fetch = [&](int o, int v) {
 #pragma unroll
-    for (int t = 0; t < TPB; ++t) cur[t] = nxt[t];
+    for (int pc = 0; pc < 1 + T::NT; ++pc) fetch_piece(o, v, pc);
+  };
+
+  fetch(0, 0);
+  fetch(0, 1);
+#pragma unroll 1
+  for (int o = 0; o < NOUT; ++o) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool last_body = (NOUT == 1) || (o + 1 == NOUT);
+      // step u's fragments are complete once at most the following step's reads remain
+      if (u + 1 < U || !last_body) wait_lgkm<NLD>();
+      else wait_lgkm<0>();
+      bool do_fetch = (u + 2 < U) || !last_body;
+      if (STAMPS && (ring.dbg & 2)) do_fetch = false;  // timing experiment: MFMAs only
+#pragma unroll
+      for (int m = 0; m < 2 * T::NT; ++m) {
+        const int mt = m / T::NT, j = m % T::NT;
+        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u % 3][mt], fb[u % 3][j], acc[mt][j], 0, 0, 0);
+        if (m < 1 + T::NT) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (do_fetch) fetch_piece(o, u + 2, m);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
   }
 }
 
@@ -350,37 +406,49 @@ __device__ __forceinline__ int acc_chan(int mt, int g4) {
 // Epilogue A: v = mish(acc * scale[c] + shift[c]) -> fp16 -> act buffer (chunk index
 // cbase/8 + ...), only for valid rows.  `cofs` = channel offset of this cout pass inside
 // the act buffer's channel space.
+// The 2 x 8 parameter quads of a layer (folded BN scale / shift of this lane's 32
+// channels).  Loaded with epi_params BEFORE the barrier that precedes the epilogue so the
+// L2 latency hides under the wait for the other waves.
+struct EpiParams { f32x4 sc[8], sh[8]; };
+
+template <class G, int COUT_PASS>
+__device__ __forceinline__ void epi_params(EpiParams& ep, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, int cofs) {
+  const int h = launder(threadIdx.x & 63) >> 5;
+  const int c0 = cofs + cg_of<G, COUT_PASS>() * 64 + h * 4;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {  // k = mt*4 + g4 -> channel c0 + 8k
+    ep.sc[k] = *(const f32x4*)(scale + c0 + 8 * k);
+    ep.sh[k] = *(const f32x4*)(shift + c0 + 8 * k);
+  }
+}
+
 template <class G, int COUT_PASS, int NTn>
 __device__ __forceinline__ void epilogue_to_act(char* smem, f32x16 (&acc)[2][NTn],
-                                                const float* __restrict__ scale,
-                                                const float* __restrict__ shift, int cofs) {
+                                                const EpiParams& ep, int cofs) {
   using T = Tiling<G, COUT_PASS>;
   const int lane = launder(threadIdx.x & 63);
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lg = wid / T::CG;
   const int lr = lane & 31, h = lane >> 5;
+  const int cblk0 = (cofs >> 3) + cg_of<G, COUT_PASS>() * 8;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int j = 0; j < T::NT; ++j) {
+    const int t = lg + j * T::LG;
+    if (t >= G::NT_TOTAL) continue;
+    const int p = t / G::NT_POS, tt = t - p * G::NT_POS;
+    const int r = tt * 32 + lr;
+    int loc;
+    const bool ok = row_valid<G::S>(r, loc);
+    const uint32_t dst = (uint32_t)((p * G::PSLOTS + G::PADTOP + r) * G::SLOTB + cblk0 * 16 + h * 8);
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int c = cofs + acc_chan<G, COUT_PASS>(mt, g4);
-      const f32x4 sc = *(const f32x4*)(scale + c);
-      const f32x4 sh = *(const f32x4*)(shift + c);
+    for (int k = 0; k < 8; ++k) {
+      const int mt = k >> 2, g4 = k & 3;
+      h4 o;
 #pragma unroll
-      for (int j = 0; j < T::NT; ++j) {
-        const int t = lg + j * T::LG;
-        if (t >= G::NT_TOTAL) continue;
-        const int p = t / G::NT_POS, tt = t - p * G::NT_POS;
-        const int r = tt * 32 + lr;
-        int loc;
-        const bool ok = row_valid<G::S>(r, loc);
-        h4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (_Float16)mish_f(acc[mt][j][g4 * 4 + i] * sc[i] + sh[i]);
-        const int s = p * G::PSLOTS + G::PADTOP + r;
-        const int ch = (c >> 3) ^ swz<G::NCH>(s);
-        if (ok) *(h4*)(smem + s * G::SLOTB + ch * 16 + h * 8) = o;
-      }
+      for (int i = 0; i < 4; ++i)
+        o[i] = (_Float16)mish_f(acc[mt][j][g4 * 4 + i] * ep.sc[k][i] + ep.sh[k][i]);
+      if (ok) *(h4*)(smem + dst + k * 16) = o;
     }
   }
 }
@@ -444,8 +512,7 @@ __device__ __forceinline__ void stage_store(char* smem, const XRegs<G>& xr, int 
     const int y = (loc * 3450) >> 16;  // loc / 19 for loc < 361
     const int xx = loc - y * kBL;
     const int sl = p * G::PSLOTS + G::PADTOP + y * G::S + xx;
-    const int ch = kc ^ swz<G::NCH>(sl);
-    *(h8*)(smem + sl * G::SLOTB + ch * 16) = o;
+    *(h8*)(smem + sl * G::SLOTB + kc * 16) = o;
     if (i & 1) __builtin_amdgcn_sched_barrier(0);  // bound the live range: 2 items in flight
   }
 }

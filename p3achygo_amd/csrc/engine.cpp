@@ -556,7 +556,7 @@ void p3hip_flops_per_position(const p3hip_engine* e, double* total, double* conv
 }
 
 // Diagnostic: runs the first btl block (C=256, L=3 only) with in-kernel phase stamps.
-// out receives grid*2*4*32 u64 (workgroup, wave {0,7}, position index, stamp id).
+// out receives grid*8*4*32 u64 (workgroup, wave, position index, stamp id).
 int p3hip_debug_block_stamps(p3hip_engine* e, int n_positions, unsigned long long* out, int max_u64) {
   const WeightFile& wf = e->wf;
   const BlockPlan* bp = nullptr;
@@ -564,13 +564,14 @@ int p3hip_debug_block_stamps(p3hip_engine* e, int n_positions, unsigned long lon
     if (b.kind == 0) { bp = &b; break; }
   if (!bp || wf.C != 256 || wf.inner != 3) { e->err = "stamps: need a C=256 btl3 net"; return 1; }
   const int grid = grid_for(e, n_positions, 1);
-  const size_t n = (size_t)grid * 2 * 4 * 32;
+  const size_t n = (size_t)grid * 8 * 4 * 32;
   if ((size_t)max_u64 < n) { e->err = "stamps: buffer too small"; return 1; }
   unsigned long long* d = nullptr;
   if (!e->check(hipMalloc((void**)&d, n * 8), "hipMalloc stamps")) return 1;
   hipMemsetAsync(d, 0, n * 8, e->stream);
   p3::BlockArgs a = block_args(e, *bp, n_positions);
   a.stamps = d;
+  a.dbg = getenv("P3HIP_DBG") ? atoi(getenv("P3HIP_DBG")) : 0;
   bool ok = e->check(p3::launch_block_stamps(a, grid, e->stream), "launch stamps") &&
             e->check(hipStreamSynchronize(e->stream), "sync") &&
             e->check(hipMemcpy(out, d, n * 8, hipMemcpyDeviceToHost), "D2H stamps");

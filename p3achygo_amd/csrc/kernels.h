@@ -32,6 +32,7 @@ struct BlockArgs {
   const float* scale[kMaxBlockLayers];  // folded BN of conv j's prologue
   const float* shift[kMaxBlockLayers];
   unsigned long long* stamps;  // diagnostic build only
+  int dbg;                     // diagnostic build only
 };
 
 struct InitArgs {

@@ -24,13 +24,13 @@ namespace p3 {
 //   reduce: for each CB-slice of C input channels; inner 3x3 convs in order; expand: for
 //   each CB-slice of C output channels.
 // =======================================================================================
-// STAMPS: diagnostic build only (p3hip_debug_block_stamps): lane 0 of waves 0 and 7 of every
+// STAMPS: diagnostic build only (p3hip_debug_block_stamps): lane 0 of each wave of every
 // workgroup stores s_memtime at each phase boundary into a.stamps (never read by the kernel).
 #define P3_STAMP(k)                                                                          \
   if (STAMPS) {                                                                              \
     const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                         \
-    if ((threadIdx.x & 63) == 0 && (w_ == 0 || w_ == 7) && npos_done < 4)                   \
-      a.stamps[((blockIdx.x * 2 + (w_ == 7)) * 4 + npos_done) * 32 + (k)] =                  \
+    if ((threadIdx.x & 63) == 0 && npos_done < 4)                                            \
+      a.stamps[((blockIdx.x * 8 + w_) * 4 + npos_done) * 32 + (k)] =                         \
           __builtin_amdgcn_s_memtime();                                                      \
   }
 
@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
   act_zero<G>(smem);
   Ring<T::RS> ring;
   ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
+  if (STAMPS) ring.dbg = a.dbg;
   lds_barrier();
 
   static_assert(C / CB == 2, "two input slices / two output passes");
@@ -73,8 +74,12 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
     if (KIND == 0) {
 #pragma unroll 1
       for (int j = 1; j <= L; ++j) {
-        lds_barrier();
-        epilogue_to_act<G, CB>(smem, acc, a.scale[j], a.shift[j], 0);
+        {
+          EpiParams ep;
+          epi_params<G, CB>(ep, a.scale[j], a.shift[j], 0);
+          lds_barrier();
+          epilogue_to_act<G, CB>(smem, acc, ep, 0);
+        }
         acc_zero<G, CB>(acc);
         P3_STAMP(3 + 2 * j);
         if (j == L) {
@@ -85,11 +90,15 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
         P3_STAMP(4 + 2 * j);
         if (STAMPS && (threadIdx.x & 63) == 0 && npos_done < 4) {
           const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-          if (w_ == 0 || w_ == 7) a.stamps[((blockIdx.x * 2 + (w_ == 7)) * 4 + npos_done) * 32 + 20 + j] = ring.wait_cycles;
+          a.stamps[((blockIdx.x * 8 + w_) * 4 + npos_done) * 32 + 20 + j] = ring.wait_cycles;
         }
       }
-      lds_barrier();
-      epilogue_to_act<G, CB>(smem, acc, a.scale[L + 1], a.shift[L + 1], 0);
+      {
+        EpiParams ep;
+        epi_params<G, CB>(ep, a.scale[L + 1], a.shift[L + 1], 0);
+        lds_barrier();
+        epilogue_to_act<G, CB>(smem, acc, ep, 0);
+      }
       P3_STAMP(11);
     } else {
       // nbt: keep the raw inner residual t in registers (fp32, same tile as acc)
@@ -100,12 +109,20 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
         for (int j = 0; j < T::NT; ++j) t[mt][j] = acc[mt][j];
 #pragma unroll 1
       for (int r = 0; r < 2; ++r) {
-        lds_barrier();
-        epilogue_to_act<G, CB>(smem, t, a.scale[1 + 2 * r], a.shift[1 + 2 * r], 0);
+        {
+          EpiParams ep;
+          epi_params<G, CB>(ep, a.scale[1 + 2 * r], a.shift[1 + 2 * r], 0);
+          lds_barrier();
+          epilogue_to_act<G, CB>(smem, t, ep, 0);
+        }
         acc_zero<G, CB>(acc);
         conv_segment<G, CB, 3, 9, STAMPS>(ring, smem, acc);
-        lds_barrier();
-        epilogue_to_act<G, CB>(smem, acc, a.scale[2 + 2 * r], a.shift[2 + 2 * r], 0);
+        {
+          EpiParams ep;
+          epi_params<G, CB>(ep, a.scale[2 + 2 * r], a.shift[2 + 2 * r], 0);
+          lds_barrier();
+          epilogue_to_act<G, CB>(smem, acc, ep, 0);
+        }
         acc_zero<G, CB>(acc);
         conv_segment<G, CB, 3, 9, STAMPS>(ring, smem, acc);
 #pragma unroll
@@ -113,8 +130,12 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
 #pragma unroll
           for (int j = 0; j < T::NT; ++j) t[mt][j] += acc[mt][j];
       }
-      lds_barrier();
-      epilogue_to_act<G, CB>(smem, t, a.scale[5], a.shift[5], 0);
+      {
+        EpiParams ep;
+        epi_params<G, CB>(ep, a.scale[5], a.shift[5], 0);
+        lds_barrier();
+        epilogue_to_act<G, CB>(smem, t, ep, 0);
+      }
       stage_load<G>(xr, a.x, C, pos_next, a.npos, 0);
       ring_note_xloads(ring);
     }
@@ -191,9 +212,8 @@ __global__ void __launch_bounds__(kWG, 2) k_init(InitArgs a) {
         if (lm[0] == y && lm[1] == xx) lo[2 + m] = (_Float16)1.0f;  // pass {19,0}/noop never match
       }
       const int s = G::PADTOP + y * G::S + xx;
-      const int sw = swz<G::NCH>(s);
-      *(h8*)(smem + s * G::SLOTB + (0 ^ sw) * 16) = lo;
-      *(h8*)(smem + s * G::SLOTB + (1 ^ sw) * 16) = hi;
+      *(h8*)(smem + s * G::SLOTB) = lo;
+      *(h8*)(smem + s * G::SLOTB + 16) = hi;
     }
     // ---- game-state scalars (LoadFeatures) ------------------------------------------
     float gsv[8];

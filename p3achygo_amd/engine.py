@@ -181,11 +181,11 @@ class HipEngine:
         return ms, fl.value, (name.value or b"").decode()
 
     def debug_block_stamps(self, n_positions: int) -> np.ndarray:
-        buf = np.zeros(256 * 2 * 4 * 32, np.uint64)
+        buf = np.zeros(256 * 8 * 4 * 32, np.uint64)
         grid = self._L.p3hip_debug_block_stamps(self._h, n_positions, buf.ctypes.data, len(buf))
         if grid <= 0:
             raise EngineError("debug_block_stamps: " + self._L.p3hip_last_error(self._h).decode())
-        return buf[:grid * 2 * 4 * 32].reshape(grid, 2, 4, 32)
+        return buf[:grid * 8 * 4 * 32].reshape(grid, 8, 4, 32)
 
     def flops_per_position(self):
         t, c = C.c_double(0), C.c_double(0)

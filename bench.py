@@ -48,7 +48,7 @@ def cpu_baseline(path, pos, budget_s=12.0):
     t0 = time.perf_counter()
     net.forward_features(pos[:cores], nthreads=cores)
     t1 = time.perf_counter() - t0
-    rounds = max(1, min(8, int(budget_s / max(t1, 1e-3))))
+    rounds = max(1, min(64, int(budget_s / max(t1, 1e-3))))
     n = cores * rounds
     sample = pos[np.arange(n) % len(pos)]
     t0 = time.perf_counter()

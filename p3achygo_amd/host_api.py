@@ -1,0 +1,126 @@
+"""ctypes access to libp3host.so (rules engine, RNG, symmetry, features, self-play host)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "host", "libp3host.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: run __graft_entry__.build()")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, u64, f32 = C.c_void_p, C.c_int, C.c_uint64, C.c_float
+        sig = {
+            "p3host_prng_new": (vp, [u64, u64, u64, u64]), "p3host_prng_free": (None, [vp]),
+            "p3host_prng_next": (C.c_uint32, [vp]), "p3host_prng_next64": (u64, [vp]),
+            "p3host_prng_next128": (None, [vp, C.POINTER(u64), C.POINTER(u64)]),
+            "p3host_rand_range": (i32, [vp, i32, i32]),
+            "p3host_prob_new": (vp, [u64]), "p3host_prob_free": (None, [vp]),
+            "p3host_prob_uniform": (f32, [vp]), "p3host_prob_gumbel": (f32, [vp]),
+            "p3host_transform_index": (i32, [i32, i32, i32]), "p3host_transform_inv": (i32, [i32, i32, i32]),
+            "p3host_board_new": (vp, [f32, i32]), "p3host_board_handicap": (vp, [i32, f32]),
+            "p3host_board_copy": (vp, [vp]), "p3host_board_free": (None, [vp]),
+            "p3host_board_play": (i32, [vp, i32, i32, i32]), "p3host_board_dry": (i32, [vp, i32, i32, i32]),
+            "p3host_board_pass": (i32, [vp, i32]), "p3host_board_place_raw": (None, [vp, i32, i32, i32]),
+            "p3host_board_is_game_over": (i32, [vp]), "p3host_board_is_all_pass_alive": (i32, [vp]),
+            "p3host_board_move_count": (i32, [vp]), "p3host_board_hash": (u64, [vp]),
+            "p3host_board_position": (None, [vp, vp]), "p3host_board_pass_alive": (None, [vp, vp]),
+            "p3host_board_calc_pass_alive": (None, [vp, i32]),
+            "p3host_board_scores": (None, [vp, C.POINTER(f32), C.POINTER(f32), vp]),
+            "p3host_board_liberties_plane": (None, [vp, i32, vp]), "p3host_board_laddered": (None, [vp, vp]),
+            "p3host_board_group_liberties": (i32, [vp, i32, i32]),
+            "p3host_board_group_id": (i32, [vp, i32, i32]),
+            "p3host_game_new": (vp, [f32]), "p3host_game_free": (None, [vp]),
+            "p3host_game_play": (i32, [vp, i32, i32, i32]), "p3host_game_num_moves": (i32, [vp]),
+            "p3host_game_features": (None, [vp, i32, i32, vp]),
+            "p3host_unapply_symmetry": (None, [i32, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class Board:
+    """Thin handle over p3::Board (cc/game/board.h surface)."""
+
+    def __init__(self, komi: float = 7.5, prohibit_pass_alive: bool = True, _h=None):
+        self._L = lib()
+        self._h = _h or self._L.p3host_board_new(komi, int(prohibit_pass_alive))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.p3host_board_free(self._h)
+            self._h = None
+
+    def copy(self):
+        return Board(_h=self._L.p3host_board_copy(self._h))
+
+    def play(self, i, j, color) -> bool:
+        return self._L.p3host_board_play(self._h, i, j, color) == 0
+
+    def play_status(self, i, j, color) -> int:
+        return self._L.p3host_board_play(self._h, i, j, color)
+
+    def dry(self, i, j, color) -> bool:
+        return self._L.p3host_board_dry(self._h, i, j, color) == 0
+
+    def dry_status(self, i, j, color) -> int:
+        return self._L.p3host_board_dry(self._h, i, j, color)
+
+    def pass_(self, color):
+        self._L.p3host_board_pass(self._h, color)
+
+    def place_raw(self, i, j, color):
+        self._L.p3host_board_place_raw(self._h, i, j, color)
+
+    def _grid(self, fn, *a):
+        out = np.zeros(361, np.int8)
+        fn(self._h, *a, out.ctypes.data)
+        return out.reshape(19, 19)
+
+    def position(self):
+        return self._grid(self._L.p3host_board_position)
+
+    def pass_alive(self):
+        return self._grid(self._L.p3host_board_pass_alive)
+
+    def calc_pass_alive(self, color=0):
+        self._L.p3host_board_calc_pass_alive(self._h, color)
+
+    def is_all_pass_alive(self) -> bool:
+        return bool(self._L.p3host_board_is_all_pass_alive(self._h))
+
+    def is_game_over(self) -> bool:
+        return bool(self._L.p3host_board_is_game_over(self._h))
+
+    def scores(self):
+        b, w = C.c_float(), C.c_float()
+        own = np.zeros(361, np.int8)
+        self._L.p3host_board_scores(self._h, C.byref(b), C.byref(w), own.ctypes.data)
+        return b.value, w.value, own.reshape(19, 19)
+
+    def liberties_plane(self, n):
+        return self._grid(self._L.p3host_board_liberties_plane, n)
+
+    def laddered(self):
+        return self._grid(self._L.p3host_board_laddered)
+
+    def group_liberties(self, i, j) -> int:
+        return self._L.p3host_board_group_liberties(self._h, i, j)
+
+    def group_id(self, i, j) -> int:
+        return self._L.p3host_board_group_id(self._h, i, j)
+
+    def hash(self) -> int:
+        return self._L.p3host_board_hash(self._h)

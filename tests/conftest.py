@@ -17,7 +17,9 @@ def built():
     """Builds libp3hip.so / liboracle.so in-tree if they are missing (cross-compiles on CPU)."""
     import __graft_entry__ as g
     from p3achygo_amd import engine
-    if not os.path.exists(engine.LIB_PATH) or not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+    need = [engine.LIB_PATH, os.path.join(ROOT, "oracle", "liboracle.so"),
+            os.path.join(ROOT, "p3achygo_amd", "host", "libp3host.so")]
+    if not all(os.path.exists(p) for p in need):
         g.build()
     return True
 

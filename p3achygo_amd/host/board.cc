@@ -83,30 +83,47 @@ Board::Board(int handicap, float komi) : Board(komi, true) {
     AddStone(idx, kBlack);
     hash_ ^= kZob.k[idx][kEmpty + 1] ^ kZob.k[idx][kBlack + 1];
   }
-  seen_.fill(0);
-  seen_count_ = 0;
+  local_n_ = 0;
+  base_.reset();
   SeenInsert(hash_);
+}
+
+bool SeenTable::Contains(uint64_t h) const {
+  for (uint32_t s = (uint32_t)mix(h) & (kCap - 1);; s = (s + 1) & (kCap - 1)) {
+    if (slot[s] == h) return true;
+    if (slot[s] == 0) return false;
+  }
+}
+
+void SeenTable::Insert(uint64_t h) {
+  if (count >= kCap / 2) return;  // unreachable within kMaxGameLen + read depth
+  for (uint32_t s = (uint32_t)mix(h) & (kCap - 1);; s = (s + 1) & (kCap - 1)) {
+    if (slot[s] == h) return;
+    if (slot[s] == 0) {
+      slot[s] = h;
+      ++count;
+      return;
+    }
+  }
 }
 
 bool Board::SeenContains(uint64_t h) const {
   if (h == 0) h = 1;
-  for (uint32_t s = (uint32_t)mix(h) & (kSeenCap - 1);; s = (s + 1) & (kSeenCap - 1)) {
-    if (seen_[s] == h) return true;
-    if (seen_[s] == 0) return false;
-  }
+  for (int i = local_n_ - 1; i >= 0; --i)
+    if (local_[i] == h) return true;
+  return base_ && base_->Contains(h);
 }
 
 void Board::SeenInsert(uint64_t h) {
   if (h == 0) h = 1;
-  if (seen_count_ >= kSeenCap - 64) return;  // cannot happen within kMaxGameLen + search depth
-  for (uint32_t s = (uint32_t)mix(h) & (kSeenCap - 1);; s = (s + 1) & (kSeenCap - 1)) {
-    if (seen_[s] == h) return;
-    if (seen_[s] == 0) {
-      seen_[s] = h;
-      ++seen_count_;
-      return;
-    }
+  if (local_n_ == kLocalCap) {  // flush the inline list into a fresh shared table
+    auto t = std::make_shared<SeenTable>();
+    if (base_) *t = *base_;
+    for (int i = 0; i < local_n_; ++i) t->Insert(local_[i]);
+    base_ = std::move(t);
+    local_n_ = 0;
   }
+  local_[local_n_++] = h;
 }
 
 int Board::EmptyNeighbors(int idx) const {  // GroupTracker::LibertiesAt, board.cc:143-152

@@ -15,6 +15,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 namespace p3 {
@@ -51,9 +52,29 @@ struct Scores {                                  // cc/game/board.h:71-75
   Grid ownership;
 };
 
+// Positional-superko history.  A Board keeps the keys of the positions it added itself in
+// a short inline list and shares everything older through an immutable open-addressed
+// table, so copying a Board (one per playout, one per ladder-reader node) costs ~3 KB.
+struct SeenTable {
+  static constexpr int kCap = 4096;   // >= 2 * (kMaxGameLen + deepest read), power of 2
+  uint64_t slot[kCap] = {};
+  int count = 0;
+  bool Contains(uint64_t h) const;
+  void Insert(uint64_t h);
+};
+
 class Board {
  public:
   explicit Board(float komi = 7.5f, bool prohibit_pass_alive = true);
+  Board(const Board& o) { *this = o; }
+  Board& operator=(const Board& o) {
+    if (this == &o) return *this;
+    std::memcpy(static_cast<void*>(&stones_), static_cast<const void*>(&o.stones_),
+                reinterpret_cast<const char*>(&o.local_) - reinterpret_cast<const char*>(&o.stones_));
+    std::memcpy(local_, o.local_, sizeof(uint64_t) * o.local_n_);
+    base_ = o.base_;
+    return *this;
+  }
   // handicap constructor, cc/game/board.cc:444-470 (2..4 stones)
   Board(int handicap, float komi);
 
@@ -111,9 +132,10 @@ class Board {
   float komi_;
   bool prohibit_pass_alive_;
   uint64_t hash_;
-  static constexpr int kSeenCap = 2048;   // > kMaxGameLen + search/ladder depth, power of 2
-  std::array<uint64_t, kSeenCap> seen_{};
-  int seen_count_ = 0;
+  int local_n_ = 0;
+  static constexpr int kLocalCap = 96;
+  uint64_t local_[kLocalCap];             // keys added by this object since the last flush
+  std::shared_ptr<const SeenTable> base_;  // older keys, shared between copies (may be null)
 };
 
 // cc/game/game.{h,cc}: a board plus the move list (five leading noop moves) and result.
@@ -149,6 +171,31 @@ class Game {
   Board board_;
   std::vector<Move> moves_;
   Result result_;
+};
+
+
+// What the search needs of a game: the board, the last five moves (network input) and the
+// move count — cheap to copy once per playout (the reference copies the whole Game with its
+// move vector and hash set: gumbel.cc:420).
+struct Position {
+  Board board;
+  Move last[5];
+  int num_moves = 0;
+  Position() { for (auto& m : last) m = Move{kEmpty, kNoopLoc}; }
+  explicit Position(const Game& g) : board(g.board()), num_moves(g.num_moves()) {
+    for (int i = 0; i < 5; ++i) last[i] = g.moves()[g.moves().size() - 5 + i];
+  }
+  float komi() const { return board.komi(); }
+  bool IsGameOver() const { return board.IsGameOver(); }
+  bool IsValidMove(Loc loc, Color c) const { return board.IsValidMove(loc, c); }
+  bool PlayMove(Loc loc, Color c) {
+    if (!MoveOk(board.PlayMove(loc, c))) return false;
+    for (int i = 0; i < 4; ++i) last[i] = last[i + 1];
+    last[4] = Move{c, loc};
+    ++num_moves;
+    return true;
+  }
+  Scores GetScores() { return board.GetScores(); }
 };
 
 }  // namespace p3

@@ -9,27 +9,26 @@
 
 namespace p3 {
 
-inline void FillFeatures(const Game& game, Color color_to_move, Symmetry sym, p3hip_features* f) {
+inline void FillFeatures(const Position& pos, Color color_to_move, Symmetry sym, p3hip_features* f) {
   f->bsize = kBoardLen;
   f->color = color_to_move;
-  f->komi = game.komi();
-  const int n = game.num_moves();
+  f->komi = pos.komi();
   for (int i = 0; i < P3HIP_NUM_LAST_MOVES; ++i) {
-    const int off = n - P3HIP_NUM_LAST_MOVES + i;
-    Loc l = kNoopLoc;
-    if (off >= 0) {
-      l = game.move(off).loc;
-      if (l != kPassLoc) l = AsLoc(TransformIndex(sym, Idx(l), kBoardLen));
-    }
+    Loc l = pos.last[i].loc;   // noop-padded at the front exactly like Game::moves()
+    if (l != kPassLoc && l != kNoopLoc) l = AsLoc(TransformIndex(sym, Idx(l), kBoardLen));
     f->last_moves[i].i = l.i;
     f->last_moves[i].j = l.j;
   }
-  const Board& b = game.board();
+  const Board& b = pos.board;
   ApplySymmetry(sym, b.position().data(), f->board, kBoardLen);
   ApplySymmetry(sym, b.GetStonesInAtari().data(), f->stones_atari, kBoardLen);
   ApplySymmetry(sym, b.GetStonesWithLiberties(2).data(), f->stones_two_liberties, kBoardLen);
   ApplySymmetry(sym, b.GetStonesWithLiberties(3).data(), f->stones_three_liberties, kBoardLen);
   ApplySymmetry(sym, b.GetLadderedStones().data(), f->stones_laddered, kBoardLen);
+}
+
+inline void FillFeatures(const Game& game, Color color_to_move, Symmetry sym, p3hip_features* f) {
+  FillFeatures(Position(game), color_to_move, sym, f);
 }
 
 // undo the symmetry on the 361-point parts of the result (pass entry 361 is untouched)

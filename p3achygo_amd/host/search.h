@@ -1,0 +1,584 @@
+// search.h — serial Gumbel MCTS of the self-play host as a RESUMABLE state machine.
+//
+// Algorithmically this restates the reference's serial search:
+//   GumbelEvaluator::SearchRoot           cc/mcts/gumbel.cc:260-559  (Gumbel top-k + sequential
+//                                         halving, improved policy, tau sampling, root update)
+//   GumbelEvaluator::Search/Backward/SingleBackup   gumbel.cc:674-821 (descent, incremental
+//                                         mean / variance / 3rd moment / histogram backup)
+//   PuctScorer::ComputeScores/TopMove     cc/mcts/search_policy.h:159-368 (non-root PUCT with FPU,
+//                                         visit-scaled c_puct, child variance scaling)
+//   LeafEvaluator::{EvaluateRoot,EvaluateLeaf,EvaluateTerminal,InitFields}
+//                                         cc/mcts/leaf_evaluator.cc:83-215
+//   TreeNode / accessors                  cc/mcts/tree.h:21-148
+// What is new is the control flow.  The reference blocks one OS thread per game inside
+// LeafEvaluator (nn_interface.cc:107-132), which caps a process at 256 games; here a search
+// is an object whose Step() runs until it needs a network evaluation, hands the position
+// out, and continues when Resume() delivers the result, so one host thread can interleave
+// hundreds of games and every GPU batch is filled from all of them.
+// Tree nodes keep children sparsely (a search at n = 32 touches a handful of the 362 moves).
+#pragma once
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <memory>
+#include <vector>
+
+#include "../../include/p3hip.h"
+#include "board.h"
+#include "rng.h"
+
+namespace p3 {
+
+constexpr float kDefaultScoreWeight = 0.5f;              // cc/mcts/constants.h:6
+constexpr float kMaxQ = 1.0f + kDefaultScoreWeight;
+constexpr float kMinQ = -1.0f - kDefaultScoreWeight;
+constexpr int kNumVBuckets = 51;
+constexpr float kBucketRange = 2.0f / kNumVBuckets;
+constexpr float kDefaultFPU = 0.2f;                      // cc/mcts/search_policy.h:17
+
+struct TreeNode;
+struct ChildEdge {
+  int16_t action;
+  int visits;
+  TreeNode* node;
+};
+
+struct TreeNode {                                        // cc/mcts/tree.h:21-91
+  bool evaluated = false;   // TreeNodeState::kNnEvaluated
+  bool is_terminal = false;
+  Color color_to_move = kEmpty;
+  int n = 0;
+  float w = 0, v = 0, v_var = 0;
+  double v_m3 = 0;
+  uint32_t v_categorical[kNumVBuckets] = {};
+  float w_outcome = 0, v_outcome = 0, v_outcome_var = 0;
+  double v_outcome_m3 = 0;
+  float score = 0, v_err = 0;
+  int max_child_n = 0;
+  std::vector<ChildEdge> children;
+  float move_logits[kNumMoves], move_probs[kNumMoves], opt_probs[kNumMoves];
+  float init_outcome_est = 0, init_score_est = 0, init_score_var = 0, init_util_est = 0, init_err_est = 0;
+  uint32_t mark = 0;  // NodePool::Reap
+
+  ChildEdge* edge(int a) {
+    for (auto& e : children)
+      if (e.action == a) return &e;
+    return nullptr;
+  }
+  const ChildEdge* edge(int a) const { return const_cast<TreeNode*>(this)->edge(a); }
+  TreeNode* child(int a) const { const ChildEdge* e = edge(a); return e ? e->node : nullptr; }
+  int child_visits(int a) const { const ChildEdge* e = edge(a); return e ? e->visits : 0; }
+};
+
+inline float N(const TreeNode* n) { return n ? (float)n->n : 0; }
+inline float V(const TreeNode* n) { return n ? n->v : kMinQ; }
+inline float VOutcome(const TreeNode* n) { return n ? n->v_outcome : -1.0f; }
+inline float Q(const TreeNode* n, int a) { const TreeNode* c = n->child(a); return c ? -c->v : kMinQ; }
+inline float QOutcome(const TreeNode* n, int a) { const TreeNode* c = n->child(a); return c ? -c->v_outcome : -1.0f; }
+inline float SumChildrenN(const TreeNode* n) { return n ? (float)(n->n - 1) : 0; }
+inline float MaxN(const TreeNode* n) { return n ? (float)n->max_child_n : 0; }
+
+// MctsNodeTable (cc/mcts/node_table.h:49-76): fresh node per request, Reap keeps what is
+// reachable from the new root (node_table.cc:12-40).
+class NodePool {
+ public:
+  TreeNode* Create() {
+    if (!free_.empty()) {
+      TreeNode* n = free_.back();
+      free_.pop_back();
+      *n = TreeNode();
+      live_.push_back(n);
+      return n;
+    }
+    owned_.emplace_back(new TreeNode());
+    live_.push_back(owned_.back().get());
+    return live_.back();
+  }
+  int Reap(TreeNode* new_root) {
+    ++epoch_;
+    std::vector<TreeNode*> work;
+    if (new_root) work.push_back(new_root);
+    while (!work.empty()) {
+      TreeNode* n = work.back();
+      work.pop_back();
+      if (n->mark == epoch_) continue;
+      n->mark = epoch_;
+      for (auto& e : n->children)
+        if (e.node) work.push_back(e.node);
+    }
+    int reaped = 0;
+    size_t keep = 0;
+    for (TreeNode* n : live_) {
+      if (n->mark == epoch_) live_[keep++] = n;
+      else { free_.push_back(n); ++reaped; }
+    }
+    live_.resize(keep);
+    return reaped;
+  }
+  void Clear() { Reap(nullptr); }
+  size_t Size() const { return live_.size(); }
+
+ private:
+  std::vector<std::unique_ptr<TreeNode>> owned_;
+  std::vector<TreeNode*> live_, free_;
+  uint32_t epoch_ = 0;
+};
+
+inline void SoftmaxN(const float* in, float* out, int n) {   // core::SoftmaxV, cc/core/vmath.h
+  float m = in[0];
+  for (int i = 1; i < n; ++i) m = std::max(m, in[i]);
+  float s = 0;
+  for (int i = 0; i < n; ++i) { out[i] = std::exp(in[i] - m); s += out[i]; }
+  for (int i = 0; i < n; ++i) out[i] /= s;
+}
+
+// ---- leaf evaluation (leaf_evaluator.cc) -------------------------------------------
+inline float ScoreTransform(float c_score, float score_est, float root_score_est) {   // :78-81
+  return c_score * (float)M_2_PI * std::atan((score_est - root_score_est) / kBoardLen);
+}
+
+inline void InitFields(const p3hip_result& r, TreeNode* node, Color color_to_move) {   // :83-112
+  std::memcpy(node->move_logits, r.move_logits, sizeof node->move_logits);
+  std::memcpy(node->move_probs, r.move_probs, sizeof node->move_probs);
+  std::memcpy(node->opt_probs, r.opt_move_probs, sizeof node->opt_probs);
+  float value_est = r.value_probs[0] * -1 + r.value_probs[1] * 1;
+  float score_est = 0, score_sq = 0;
+  for (int i = 0; i < P3HIP_NUM_SCORE_LOGITS; ++i) {
+    float s = i - 400 + .5f, p = r.score_probs[i];
+    score_est += p * s;
+    score_sq += p * s * s;
+  }
+  node->color_to_move = color_to_move;
+  node->init_outcome_est = value_est;
+  node->init_score_est = score_est;
+  node->init_score_var = score_sq - score_est * score_est;
+  node->init_err_est = std::sqrt(r.err2_outcome);
+  node->evaluated = true;
+}
+
+inline void EvaluateRoot(const p3hip_result& r, TreeNode* node, Color c) {   // :131-150
+  InitFields(r, node, c);
+  node->init_util_est = node->init_outcome_est;
+  node->n = 1;
+  node->w = node->v = node->init_util_est;
+  node->w_outcome = node->v_outcome = node->init_outcome_est;
+  node->v_err = node->init_err_est;
+  int b = std::clamp((int)((node->init_util_est + 1.0f) / kBucketRange), 0, kNumVBuckets - 1);
+  node->v_categorical[b] += 1;
+}
+
+inline void EvaluateLeaf(const p3hip_result& r, TreeNode* node, Color c, Color root_color,
+                         float root_score_est) {   // :152-162 (ScoreUtilityMode::kDirect)
+  InitFields(r, node, c);
+  root_score_est *= c == root_color ? 1.0f : -1.0f;
+  node->init_util_est = node->init_outcome_est + ScoreTransform(kDefaultScoreWeight, node->init_score_est, root_score_est);
+}
+
+inline void EvaluateTerminal(const Scores& s, TreeNode* node, Color c, Color root_color,
+                             float root_score_est) {   // :164-186
+  float ps = c == kBlack ? s.black_score : s.white_score;
+  float os = c == kBlack ? s.white_score : s.black_score;
+  float final_score = ps - os;
+  root_score_est *= c == root_color ? 1.0f : -1.0f;
+  float su = ScoreTransform(kDefaultScoreWeight, final_score, root_score_est);
+  node->color_to_move = c;
+  node->is_terminal = true;
+  node->init_util_est = (ps > os ? 1.0f : -1.0f) + su;
+  node->init_outcome_est = ps > os ? 1.0f : -1.0f;
+  node->init_score_est = final_score;
+}
+
+// ---- non-root PUCT (search_policy.h:159-368, IdentityQ / IdentityN) -----------------
+struct PuctParams {
+  float c_puct = 1.0f, c_puct_visit_scaling = 0.45f;
+  bool enable_var_scaling = false;
+  int var_scale_prior_visits = 0;
+};
+
+inline int PuctTopMove(const TreeNode* node, const Board& board, Color color, const PuctParams& pp) {
+  const int n = node->n;
+  const float v = node->v;
+  int cv[kNumMoves] = {};
+  float qs[kNumMoves], qvars[kNumMoves];
+  float q_std_weighted = 0;
+  for (const ChildEdge& e : node->children) {
+    cv[e.action] = e.visits;
+    if (e.visits > 0) qs[e.action] = -e.node->v;
+    if (e.visits >= 3) {
+      qvars[e.action] = e.node->v_var;
+      q_std_weighted += std::sqrt(qvars[e.action]) * e.visits;
+    }
+  }
+  const float q_std_mean = q_std_weighted / n;
+  float p_explored = 0;
+  for (const ChildEdge& e : node->children)
+    if (e.visits > 0) p_explored += node->move_probs[e.action];
+  const float v_fpu = v - kDefaultFPU * std::sqrt(p_explored);
+  const float c_puct = pp.c_puct + pp.c_puct_visit_scaling * std::log((n + 500.0f) / 500.0f);
+  float total_n = 1;
+  for (const ChildEdge& e : node->children) total_n += e.visits;
+  const float sqrt_n = std::sqrt(total_n);
+  float best = -1e6f;
+  int best_a = -1;
+  for (int a = 0; a < kNumMoves; ++a) {
+    float scale = 1.0f;
+    if (pp.enable_var_scaling && cv[a] >= 3 && q_std_mean != 0) {
+      const float pw = (float)pp.var_scale_prior_visits;
+      scale = (pw + cv[a] * (std::sqrt(qvars[a]) / q_std_mean)) / (pw + cv[a]);
+    }
+    const float explore = c_puct * scale * node->move_probs[a] * (sqrt_n / (1 + cv[a]));
+    const float score = explore + (cv[a] > 0 ? qs[a] : v_fpu);
+    if (score > best) {
+      Loc mv = a == kPassEncoding ? kPassLoc : AsLoc(a);
+      if (board.IsValidMove(mv, color)) {   // TopMove, search_policy.h:353-368
+        best = score;
+        best_a = a;
+      }
+    }
+  }
+  return best_a;
+}
+
+// ---- Gumbel root search ----------------------------------------------------------------
+struct GumbelParams {   // GumbelSearchParams, cc/mcts/gumbel.h:41-57
+  int n = 32, k = 4;
+  float noise_scaling = 1.0f;
+  bool disable_pass = false;
+  float tau = 0.0f;
+  int nonroot_var_scale_prior_visits = 10;
+};
+
+struct GumbelResult {   // cc/mcts/gumbel.h:31-39 (subset)
+  Loc nn_move = kNoopLoc, mcts_move = kNoopLoc;
+  float pi_improved[kNumMoves];
+  float kld = 0;
+  uint32_t visits = 0;
+};
+
+inline Loc MoveLoc(int a) { return a == kPassEncoding ? kPassLoc : AsLoc(a); }
+inline int MoveIdx(Loc l) { return l == kPassLoc ? kPassEncoding : Idx(l); }
+
+class GumbelSearch {
+ public:
+  enum class Status { kNeedEval, kDone };
+
+  // `game`, `pool`, `prob` must outlive the search.  `root` must belong to `pool`.
+  void Begin(Game* game, NodePool* pool, TreeNode* root, Color color, const GumbelParams& p,
+             Probability* prob) {
+    game_ = game; pool_ = pool; root_ = root; color_ = color; p_ = p; prob_ = prob;
+    root_pos_ = Position(*game);
+    state_ = root->evaluated ? State::kPrepare : State::kRootEval;
+    res_ = GumbelResult();
+  }
+
+  // Runs until an evaluation is needed (then eval_game()/eval_color() name the position) or
+  // the search is complete (result()).
+  Status Step() {
+    for (;;) {
+      switch (state_) {
+        case State::kRootEval:
+          eval_game_ = &root_pos_;
+          eval_color_ = color_;
+          state_ = State::kRootEvalWait;
+          return Status::kNeedEval;
+        case State::kRootEvalWait:   // Resume() stored the result
+          EvaluateRoot(pending_, root_, color_);
+          state_ = State::kPrepare;
+          break;
+        case State::kPrepare:
+          if (Prepare()) { state_ = State::kDone; return Status::kDone; }
+          state_ = State::kNextVisit;
+          break;
+        case State::kNextVisit:
+          if (!AdvanceLoop()) { Finish(); state_ = State::kDone; return Status::kDone; }
+          if (StartVisit()) return Status::kNeedEval;   // else visit completed synchronously
+          break;
+        case State::kLeafEvalWait:
+          EvaluateLeaf(pending_, path_.back().node, leaf_color_, color_, root_->init_score_est);
+          CompleteVisit();
+          state_ = State::kNextVisit;
+          break;
+        case State::kDone:
+          return Status::kDone;
+      }
+    }
+  }
+  void Resume(const p3hip_result& r) { pending_ = r; }
+  const Position* eval_game() const { return eval_game_; }
+  Color eval_color() const { return eval_color_; }
+  const GumbelResult& result() const { return res_; }
+
+ private:
+  enum class State { kRootEval, kRootEvalWait, kPrepare, kNextVisit, kLeafEvalWait, kDone };
+  struct MoveInfo { float prob = 0, logit = 0, noise = 0, qtransform = 0; int enc = -1; };
+  struct PathEntry { int action; TreeNode* node; };
+  static constexpr float kSmallLogit = -10000;
+  static constexpr int kVisit = 50;
+
+  static int ilog2(int x) { int i = 1; while ((x >> i) > 0) ++i; return i - 1; }
+  static bool Greater(const MoveInfo& x, const MoveInfo& y) {
+    return x.logit + x.noise + x.qtransform > y.logit + y.noise + y.qtransform;
+  }
+
+  // gumbel.cc:268-330: legal-move mask, Gumbel noise, top-k.  Returns true when n == 1.
+  bool Prepare() {
+    k_ = p_.k;
+    num_rounds_ = std::max(ilog2(k_), 1);
+    int k_valid = 0;
+    for (int i = 0; i < kNumMoves; ++i) {
+      gm_[i] = MoveInfo();
+      if ((p_.disable_pass && i == kPassEncoding) || !root_pos_.IsValidMove(MoveLoc(i), color_)) {
+        masked_logits_[i] = kSmallLogit;
+        gm_[i].logit = kSmallLogit;
+        continue;
+      }
+      masked_logits_[i] = root_->move_logits[i];
+      gm_[i].prob = root_->move_probs[i];
+      gm_[i].logit = root_->move_logits[i];
+      gm_[i].noise = p_.noise_scaling * prob_->GumbelSample();
+      gm_[i].enc = i;
+      ++k_valid;
+    }
+    k_ = std::min(k_valid, k_);
+    std::sort(gm_, gm_ + kNumMoves, Greater);
+    int amax = 0;
+    for (int i = 1; i < kNumMoves; ++i)
+      if (root_->move_logits[i] > root_->move_logits[amax]) amax = i;
+    res_.nn_move = MoveLoc(amax);
+    if (p_.n == 1) {
+      res_.mcts_move = MoveLoc(gm_[0].enc);
+      std::memcpy(res_.pi_improved, root_->move_probs, sizeof res_.pi_improved);
+      return true;
+    }
+    top_k_.assign(gm_, gm_ + k_);
+    theoretical_winner_visits_ = 0;
+    for (int kt = k_; kt > 1; kt /= 2)
+      theoretical_winner_visits_ += (int)std::round(float(p_.n) / float(num_rounds_ * kt));
+    m_ = k_;
+    visits_spent_ = 0;
+    round_open_ = false;
+    return false;
+  }
+
+  // advances (round, visit, candidate) to the next candidate to visit; false when k <= 1.
+  bool AdvanceLoop() {
+    for (;;) {
+      if (!round_open_) {
+        if (k_ <= 1) return false;
+        visits_per_action_ = (int)std::round(float(p_.n) / float(num_rounds_ * k_));
+        visit_num_ = 0;
+        cand_ = 0;
+        round_open_ = true;
+        if (visits_per_action_ <= 0) { CloseRound(); continue; }
+      }
+      if (cand_ >= k_) { cand_ = 0; ++visit_num_; }
+      if (visit_num_ >= visits_per_action_) { CloseRound(); continue; }
+      if (gm_[cand_].enc < 0) { ++cand_; continue; }
+      return true;
+    }
+  }
+  void CloseRound() {   // gumbel.cc:470-473
+    for (int i = 0; i < k_; ++i)
+      if (gm_[i].enc >= 0) gm_[i].qtransform = (kVisit + MaxN(root_)) * -V(root_->child(gm_[i].enc));
+    std::sort(gm_, gm_ + k_, Greater);
+    k_ /= 2;
+    round_open_ = false;
+  }
+
+  TreeNode* GetOrCreateChild(TreeNode* parent, int a) {
+    ChildEdge* e = parent->edge(a);
+    if (!e) {
+      parent->children.push_back(ChildEdge{(int16_t)a, 0, pool_->Create()});
+      e = &parent->children.back();
+    }
+    return e->node;
+  }
+
+  // one playout for candidate cand_ (gumbel.cc:412-452 + Search :674-727).  Returns true if
+  // it stopped at an unevaluated leaf (evaluation requested).
+  bool StartVisit() {
+    const int a0 = gm_[cand_].enc;
+    search_game_ = root_pos_;
+    search_game_.PlayMove(MoveLoc(a0), color_);
+    TreeNode* child = GetOrCreateChild(root_, a0);
+    path_.clear();
+    path_.push_back(PathEntry{-1, child});
+    Color c = Opp(color_);
+    PuctParams pp;
+    pp.enable_var_scaling = p_.nonroot_var_scale_prior_visits >= 0;
+    pp.var_scale_prior_visits = pp.enable_var_scaling ? p_.nonroot_var_scale_prior_visits : 0;
+    while (path_.back().node->evaluated && !path_.back().node->is_terminal && !search_game_.IsGameOver()) {
+      TreeNode* node = path_.back().node;
+      int a = PuctTopMove(node, search_game_.board, c, pp);
+      if (a < 0) a = kPassEncoding;
+      search_game_.PlayMove(MoveLoc(a), c);
+      TreeNode* nx = GetOrCreateChild(node, a);
+      path_.back().action = a;
+      path_.push_back(PathEntry{-1, nx});
+      c = Opp(c);
+    }
+    leaf_color_ = c;
+    TreeNode* leaf = path_.back().node;
+    if (!leaf->evaluated && !search_game_.IsGameOver()) {
+      eval_game_ = &search_game_;
+      eval_color_ = c;
+      state_ = State::kLeafEvalWait;
+      return true;
+    }
+    if (!leaf->evaluated) leaf->evaluated = true;   // terminal leaves carry no policy
+    CompleteVisit();
+    return false;
+  }
+
+  void CompleteVisit() {
+    TreeNode* leaf = path_.back().node;
+    if (search_game_.IsGameOver() && !leaf->is_terminal) {
+      Scores s = search_game_.GetScores();
+      EvaluateTerminal(s, leaf, leaf_color_, color_, root_->init_score_est);
+      leaf->evaluated = true;
+    }
+    Backward();
+    root_->edge(gm_[cand_].enc)->visits += 1;
+    ++visits_spent_;
+    ++cand_;
+  }
+
+  void Backward() {   // gumbel.cc:738-754
+    TreeNode* leaf = path_.back().node;
+    const float lq = leaf->init_util_est, lqo = leaf->init_outcome_est, ls = leaf->init_score_est;
+    for (int i = (int)path_.size() - 1; i >= 0; --i) {
+      TreeNode* parent = path_[i].node;
+      const float mult = leaf->color_to_move == parent->color_to_move ? 1.0f : -1.0f;
+      SingleBackup(parent, path_[i].action, i == (int)path_.size() - 1, mult * lq, mult * lqo, mult * ls);
+    }
+  }
+
+  static void SingleBackup(TreeNode* node, int a, bool is_leaf, float leaf_q, float leaf_qo, float leaf_score) {
+    if (is_leaf) {   // gumbel.cc:760-767
+      node->n += 1;
+      node->w = node->v = node->init_util_est;
+      node->w_outcome = node->v_outcome = node->init_outcome_est;
+      return;
+    }
+    const float v_old = node->v, vo_old = node->v_outcome, n_old = (float)node->n;
+    node->n += 1;
+    ChildEdge* e = node->edge(a);
+    e->visits += 1;
+    node->w += leaf_q;
+    node->w_outcome += leaf_qo;
+    node->v = node->w / node->n;
+    node->v_outcome = node->w_outcome / node->n;
+    const float nn = (float)node->n;
+    node->score = leaf_score * (1.0f / nn) + node->score * ((nn - 1.0f) / nn);
+    auto m3f = [](double m3, double m2, double d, double n) {
+      const double d3 = d * d * d;
+      return m3 + ((n * n - 1) * d3 / (n * n)) - (3 * d * m2 / n);
+    };
+    const float m3 = (float)m3f(node->v_m3 * n_old, node->v_var * n_old, leaf_q - node->v, n_old);
+    const float m3o = (float)m3f(node->v_outcome_m3 * n_old, node->v_outcome_var * n_old, leaf_qo - node->v_outcome, n_old);
+    node->v_m3 = m3 / node->n;
+    node->v_outcome_m3 = m3o / node->n;
+    node->v_var = (n_old * node->v_var + (leaf_q - v_old) * (leaf_q - node->v)) / node->n;
+    node->v_outcome_var = (n_old * node->v_outcome_var + (leaf_qo - vo_old) * (leaf_qo - node->v_outcome)) / node->n;
+    if (e->visits > node->max_child_n) node->max_child_n = e->visits;
+    int b = std::clamp((int)((leaf_qo + 1.0f) / kBucketRange), 0, kNumVBuckets - 1);
+    node->v_categorical[b] += 1;
+  }
+
+  float VMixed(const TreeNode* node) const {   // gumbel.cc:68-87
+    if (SumChildrenN(node) == 0) return node->init_util_est;
+    double wq = 0, vp = 0;
+    for (const ChildEdge& e : node->children)
+      if (e.visits > 0) { wq += node->move_probs[e.action] * -e.node->v; vp += node->move_probs[e.action]; }
+    double iq = wq * SumChildrenN(node) / vp + node->init_util_est;
+    return (float)(iq / (1 + SumChildrenN(node)));
+  }
+
+  void Finish() {   // gumbel.cc:476-559
+    const float max_n = 2 * std::log((float)(theoretical_winner_visits_ + 1));
+    auto q_norm = [](float q) { return (q + 1.1f) / 2.2f; };
+    const float v_mix = q_norm(VMixed(root_));
+    float logits[kNumMoves];
+    for (int a = 0; a < kNumMoves; ++a) {
+      bool visited = false;
+      for (const MoveInfo& t : top_k_) visited |= t.enc == a;
+      float q = visited ? q_norm(Q(root_, a)) : v_mix;
+      logits[a] = masked_logits_[a] + (kVisit + max_n) * q;
+    }
+    SoftmaxN(logits, res_.pi_improved, kNumMoves);
+    int mcts = gm_[0].enc;
+    if (p_.tau > 0.0f) mcts = SampleFromPolicy(res_.pi_improved, p_.tau);
+    res_.mcts_move = MoveLoc(mcts);
+    // root bookkeeping: all child visits, q only from the chosen move
+    int total = 0;
+    for (int i = 0; i < m_; ++i) {
+      const int a = gm_[i].enc;
+      if (a < 0) continue;
+      const int cn = root_->child_visits(a);
+      total += cn;
+      if (a == mcts && cn > 0) {
+        const float cq = Q(root_, a), cqz = QOutcome(root_, a);
+        root_->w += cn * cq;
+        root_->w_outcome += cn * cqz;
+        const int tv = root_->n + cn;
+        const float rr = root_->n / (float)tv, cr = cn / (float)tv;
+        root_->v = rr * root_->v + cr * cq;
+        root_->v_outcome = rr * root_->v_outcome + cr * cqz;
+        const TreeNode* ch = root_->child(a);
+        if (ch && root_->n + cn - 2 > 0) {
+          root_->v_outcome_var = ((root_->n - 1) * root_->v_outcome_var + (cn - 1) * ch->v_outcome_var) / (root_->n + cn - 2);
+          root_->v_var = ((root_->n - 1) * root_->v_var + (cn - 1) * ch->v_var) / (root_->n + cn - 2);
+        }
+        if (ch)
+          for (int b = 0; b < kNumVBuckets; ++b) root_->v_categorical[b] += ch->v_categorical[kNumVBuckets - b - 1];
+      }
+    }
+    root_->n = total;
+    double kld = 0;
+    for (int i = 0; i < kNumMoves; ++i)
+      if (res_.pi_improved[i] != 0.0f) kld += res_.pi_improved[i] * std::log(res_.pi_improved[i] / (root_->move_probs[i] + 1e-10));
+    res_.kld = (float)kld;
+    res_.visits = visits_spent_;
+  }
+
+  int SampleFromPolicy(const float* policy, float tau) {   // gumbel.cc:103-154
+    float tempered[kNumMoves], total = 0;
+    for (int a = 0; a < kNumMoves; ++a) { tempered[a] = std::pow(policy[a], 1.0f / tau); total += tempered[a]; }
+    const float p = prob_->Uniform();
+    float mass = 0;
+    int last = -1;
+    if (std::isfinite(total) && total > 0)
+      for (int a = 0; a < kNumMoves; ++a) {
+        if (tempered[a] == 0.0f || !std::isfinite(tempered[a])) continue;
+        last = a;
+        const float pr = tempered[a] / total;
+        if (p >= mass && p < mass + pr) return a;
+        mass += pr;
+      }
+    return last >= 0 ? last : kPassEncoding;
+  }
+
+  Game* game_ = nullptr;
+  NodePool* pool_ = nullptr;
+  TreeNode* root_ = nullptr;
+  Color color_ = kBlack;
+  GumbelParams p_;
+  Probability* prob_ = nullptr;
+  State state_ = State::kDone;
+  GumbelResult res_;
+  MoveInfo gm_[kNumMoves];
+  std::vector<MoveInfo> top_k_;
+  float masked_logits_[kNumMoves];
+  int k_ = 0, m_ = 0, num_rounds_ = 1, visits_per_action_ = 0, visit_num_ = 0, cand_ = 0;
+  int theoretical_winner_visits_ = 0;
+  uint32_t visits_spent_ = 0;
+  bool round_open_ = false;
+  Position root_pos_, search_game_;
+  std::vector<PathEntry> path_;
+  Color leaf_color_ = kBlack;
+  const Position* eval_game_ = nullptr;
+  Color eval_color_ = kBlack;
+  p3hip_result pending_;
+};
+
+}  // namespace p3

@@ -1,0 +1,513 @@
+// selfplay.cc — the self-play driver: thousands of concurrent games, their search leaves
+// coalesced into large inference batches for the engine behind include/p3hip.h.
+//
+// Game loop restated from selfplay::Run (cc/selfplay/self_play_thread.cc:309-920), core part:
+// raw-policy opening moves, playout-cap randomisation (full search with probability 0.25,
+// otherwise a fast search with per-game k and noise scaling), temperature schedule, Gumbel
+// root search, tree reuse + Reap, pass-alive refresh at moves 200/250/.../400, max_moves,
+// final scoring.  Not restated this round: GoExploit/regret reuse buffer,
+// ForkManager, opening book, handicap games, sel_mult, bias cache, the PUCT fast-search
+// variant, resignation bookkeeping, recorders.
+//
+// Scheduling is new (the reference runs one OS thread per game and a 400 us batching
+// timeout, nn_interface.cc:279-404): games are resumable state machines (search.h) split in
+// two halves, each half bound to its own engine instance; while the GPU evaluates the leaves
+// of half A, a pool of host threads consumes the results of half B, advances those games to
+// their next leaf and loads the next batch — so every batch holds one leaf of (nearly)
+// every game of its half and the GPU never waits for a timeout.
+#include <dlfcn.h>
+
+#include <functional>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "features.h"
+#include "search.h"
+
+namespace p3 {
+
+// ---- evaluator boundary (mirrors nn::Engine, cc/nn/engine/engine.h:22-43) -------------
+struct Evaluator {
+  virtual ~Evaluator() = default;
+  virtual void Load(int slot, const p3hip_features& f) = 0;
+  virtual bool Run() = 0;
+  virtual void Get(int slot, p3hip_result& r) = 0;
+};
+
+// Uniform policy, even outcome, zero score: the reference's NullEngine
+// (cc/mcts/__tests__/search_test.cc:49-65).  Lets the host be tested without a GPU.
+struct NullEvaluator final : Evaluator {
+  void Load(int, const p3hip_features&) override {}
+  bool Run() override { return true; }
+  void Get(int, p3hip_result& r) override {
+    for (int i = 0; i < kNumMoves; ++i) {
+      r.move_logits[i] = 0.0f;
+      r.move_probs[i] = 1.0f / kNumMoves;
+      r.opt_move_probs[i] = 1.0f / kNumMoves;
+    }
+    r.value_probs[0] = r.value_probs[1] = 0.5f;
+    for (int i = 0; i < P3HIP_NUM_SCORE_LOGITS; ++i) r.score_probs[i] = 0.0f;
+    r.score_probs[400] = 1.0f;
+    r.err2_outcome = 0.0f;
+  }
+};
+
+// The HIP engine, bound through its C ABI exactly as a foreign host would bind it.
+struct HipEvaluator final : Evaluator {
+  void* lib = nullptr;
+  p3hip_engine* eng = nullptr;
+  decltype(&p3hip_create) create = nullptr;
+  decltype(&p3hip_destroy) destroy = nullptr;
+  decltype(&p3hip_load_slot) load = nullptr;
+  decltype(&p3hip_run) run = nullptr;
+  decltype(&p3hip_get_slot) get = nullptr;
+  decltype(&p3hip_last_error) last_error = nullptr;
+  decltype(&p3hip_create_error) create_error = nullptr;
+  std::string err;
+
+  bool Open(const char* lib_path, const char* weights, int batch, int device) {
+    lib = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { err = dlerror(); return false; }
+    create = (decltype(create))dlsym(lib, "p3hip_create");
+    destroy = (decltype(destroy))dlsym(lib, "p3hip_destroy");
+    load = (decltype(load))dlsym(lib, "p3hip_load_slot");
+    run = (decltype(run))dlsym(lib, "p3hip_run");
+    get = (decltype(get))dlsym(lib, "p3hip_get_slot");
+    last_error = (decltype(last_error))dlsym(lib, "p3hip_last_error");
+    create_error = (decltype(create_error))dlsym(lib, "p3hip_create_error");
+    if (!create || !destroy || !load || !run || !get) { err = "missing p3hip symbols"; return false; }
+    eng = create(weights, batch, 1, device, 0);
+    if (!eng) { err = create_error ? create_error() : "p3hip_create failed"; return false; }
+    return true;
+  }
+  ~HipEvaluator() override {
+    if (eng) destroy(eng);
+    if (lib) dlclose(lib);
+  }
+  void Load(int slot, const p3hip_features& f) override { load(eng, slot, &f); }
+  bool Run() override {
+    if (run(eng) != 0) { err = last_error(eng); return false; }
+    return true;
+  }
+  void Get(int slot, p3hip_result& r) override { get(eng, slot, &r); }
+};
+
+// ---- one game ----------------------------------------------------------------------------
+struct SelfPlayConfig {       // SPConfig, cc/selfplay/self_play_thread.h:38-61 (subset)
+  int selected_n = 128, selected_k = 8;   // --gumbel_selected_{n,k}  selfplay/main.cc:40-43
+  int default_n = 32, default_k = 5;      // --gumbel_default_{n,k}   selfplay/main.cc:44-47
+  int max_moves = 600;                    // --max_moves
+  int nonroot_var_scale_prior_visits = 10;
+  float komi = 7.5f;
+  bool raw_policy_opening = true;
+};
+
+constexpr int kMaxNumRawPolicyMoves = 30;              // self_play_thread.cc:45
+constexpr float kMoveSelectedForTrainingProb = 0.25f;  // :62
+constexpr int kComputePAMoveNums[] = {200, 250, 300, 350, 400};   // :56
+
+struct GameStats {
+  long moves = 0, games = 0, evals = 0, black_wins = 0;
+};
+
+class GameRunner {
+ public:
+  GameRunner(const SelfPlayConfig& cfg, uint64_t seed) : cfg_(cfg), prob_(seed), seed_(seed) { NewGame(); }
+
+  // Advances this game until it needs a network evaluation; writes the features of the
+  // position to evaluate into *f.
+  void AdvanceToEval(p3hip_features* f) {
+    for (;;) {
+      if (search_.Step() == GumbelSearch::Status::kNeedEval) {
+        sym_ = RandomSymmetry(prob_.prng());   // nn_interface.cc:123
+        FillFeatures(*search_.eval_game(), search_.eval_color(), sym_, f);
+        ++stats_.evals;
+        return;
+      }
+      FinishMove();
+    }
+  }
+  void DeliverResult(p3hip_result& r) {
+    UnapplySymmetry(sym_, &r);   // nn_interface.h:263-288
+    search_.Resume(r);
+  }
+  const GameStats& stats() const { return stats_; }
+  const Game& game() const { return *game_; }
+  const std::vector<Move>& last_moves() const { return last_moves_; }
+  const Game::Result& last_result() const { return last_result_; }
+
+ private:
+  void NewGame() {
+    game_.reset(new Game(cfg_.komi, true));
+    pool_.Clear();
+    color_ = kBlack;
+    root_ = pool_.Create();
+    // per-game draws, self_play_thread.cc:364-368,413-423
+    const int max_raw = kMaxNumRawPolicyMoves;
+    num_moves_raw_policy_ = cfg_.raw_policy_opening ? RandRange(prob_.prng(), 0, max_raw) : 0;
+    (void)prob_.Uniform();   // use_puct_fast_search draw (variant not restated; keeps the stream aligned)
+    fast_move_noise_scaling_ = prob_.Uniform() / 1.4f;
+    {
+      int num_rounds = (int)std::log2((double)cfg_.default_k);
+      int min_k = 1 << num_rounds;
+      fast_move_gumbel_k_ = RandRange(prob_.prng(), min_k, cfg_.default_k + 1);
+    }
+    (void)prob_.Uniform();   // fast_move_root_fpu draw
+    BeginSearch();
+  }
+
+  void BeginSearch() {
+    const bool sampling_raw_policy = game_->num_moves() < num_moves_raw_policy_;
+    const float select_prob = sampling_raw_policy ? 0.0f : kMoveSelectedForTrainingProb;
+    const bool selected = prob_.Uniform() < select_prob;   // self_play_thread.cc:536-537
+    (void)prob_.Uniform();                                  // over-search draw (dead code, :538-540)
+    GumbelParams p;
+    p.nonroot_var_scale_prior_visits = cfg_.nonroot_var_scale_prior_visits;
+    if (sampling_raw_policy) {
+      p.n = 1; p.k = 1;
+    } else if (selected) {
+      p.n = cfg_.selected_n; p.k = cfg_.selected_k;
+    } else {
+      p.n = cfg_.default_n; p.k = fast_move_gumbel_k_; p.noise_scaling = fast_move_noise_scaling_;
+    }
+    {   // tau schedule, self_play_thread.cc:570-582
+      const int non_sample = game_->num_moves() - num_moves_raw_policy_;
+      const float lambda = std::log(2.0f) / 19;
+      p.tau = std::min(std::max(0.8f * std::exp(-lambda * non_sample), 0.2f), 0.8f);
+    }
+    search_.Begin(game_.get(), &pool_, root_, color_, p, &prob_);
+  }
+
+  void FinishMove() {
+    const GumbelResult& res = search_.result();
+    const Loc move = res.mcts_move;
+    game_->PlayMove(move, color_);
+    ++stats_.moves;
+    for (int m : kComputePAMoveNums)
+      if (game_->num_moves() == m) game_->mutable_board().CalculatePassAliveRegions();
+    color_ = Opp(color_);
+    TreeNode* next = root_->child(MoveIdx(move));
+    if (!next) next = pool_.Create();
+    pool_.Reap(next);   // self_play_thread.cc:711-722
+    root_ = next;
+    if (game_->IsGameOver() || game_->num_moves() >= cfg_.max_moves) {
+      game_->WriteResult();
+      ++stats_.games;
+      if (game_->result().winner == kBlack) ++stats_.black_wins;
+      last_result_ = game_->result();
+      last_moves_ = game_->moves();
+      NewGame();
+      return;
+    }
+    if (root_->is_terminal) {   // cannot happen while the game is not over; defensive reset
+      root_ = pool_.Create();
+      pool_.Reap(root_);
+    }
+    BeginSearch();
+  }
+
+  SelfPlayConfig cfg_;
+  Probability prob_;
+  uint64_t seed_;
+  std::unique_ptr<Game> game_;
+  NodePool pool_;
+  TreeNode* root_ = nullptr;
+  Color color_ = kBlack;
+  GumbelSearch search_;
+  Symmetry sym_ = kIdentity;
+  int num_moves_raw_policy_ = 0, fast_move_gumbel_k_ = 4;
+  float fast_move_noise_scaling_ = 1.0f;
+  GameStats stats_;
+  Game::Result last_result_;
+  std::vector<Move> last_moves_;
+};
+
+// ---- scheduler -----------------------------------------------------------------------------
+class WorkerPool {
+ public:
+  explicit WorkerPool(int n) {
+    for (int i = 0; i < n; ++i) threads_.emplace_back([this] { Loop(); });
+  }
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  // runs fn(i) for i in [0, n) on the pool and returns when all are done
+  template <class F>
+  void ParallelFor(int n, F&& fn) {
+    std::function<void(int)> f = fn;
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      job_ = &f;
+      next_.store(0);
+      total_ = n;
+      pending_ = (int)threads_.size();
+      ++gen_;
+    }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> l(mu_);
+    done_cv_.wait(l, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void Loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      std::function<void(int)>* job;
+      {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+        job = job_;
+      }
+      for (;;) {
+        int i = next_.fetch_add(1);
+        if (i >= total_) break;
+        (*job)(i);
+      }
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        if (--pending_ == 0) done_cv_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::function<void(int)>* job_ = nullptr;
+  std::atomic<int> next_{0};
+  int total_ = 0, pending_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+struct Half {
+  std::unique_ptr<Evaluator> eval;
+  std::vector<std::unique_ptr<GameRunner>> games;
+  std::thread gpu;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool run_requested = false, run_done = false, quit = false, ok = true;
+  double gpu_seconds = 0;
+  long runs = 0;
+};
+
+}  // namespace p3
+
+using namespace p3;
+
+extern "C" {
+
+struct p3host_selfplay_stats {
+  double seconds;            // wall time of the measured region
+  long positions;            // network evaluations (engine slots loaded)
+  long moves, games, black_wins;
+  long batches;              // engine runs
+  double gpu_seconds;        // time spent inside Evaluator::Run, summed over both halves
+  double host_seconds;       // time spent advancing games (both halves, wall)
+};
+
+// Runs self-play for about `seconds` (after `warmup_batches` unmeasured batches per half).
+// engine_lib: path of libp3hip.so, or NULL/"" for the NullEvaluator (uniform policy).
+// Returns 0 on success; `err` (256 bytes) receives a message otherwise.
+int p3host_selfplay_run(const char* engine_lib, const char* weights, int device, int num_games,
+                        int num_threads, int default_n, int default_k, int selected_n,
+                        int selected_k, int max_moves, double seconds, int warmup_batches,
+                        uint64_t seed, p3host_selfplay_stats* out, char* err) {
+  if (num_games < 2) num_games = 2;
+  SelfPlayConfig cfg;
+  cfg.default_n = default_n; cfg.default_k = default_k;
+  cfg.selected_n = selected_n; cfg.selected_k = selected_k;
+  cfg.max_moves = max_moves;
+  Half halves[2];
+  const bool use_null = !engine_lib || !engine_lib[0];
+  for (int h = 0; h < 2; ++h) {
+    const int ng = num_games / 2 + (h == 0 ? num_games % 2 : 0);
+    if (use_null) {
+      halves[h].eval.reset(new NullEvaluator());
+    } else {
+      auto* e = new HipEvaluator();
+      halves[h].eval.reset(e);
+      if (!e->Open(engine_lib, weights, ng, device)) {
+        if (err) snprintf(err, 256, "%s", e->err.c_str());
+        return 1;
+      }
+    }
+    for (int g = 0; g < ng; ++g) {
+      // documented per-game seed (replaces absl::HashOf(worker_id, thread_id), main.cc:244)
+      uint64_t s = seed * 0x9E3779B97F4A7C15ull + (uint64_t)(h * 1000003 + g) * 0xBF58476D1CE4E5B9ull;
+      halves[h].games.emplace_back(new GameRunner(cfg, s));
+    }
+  }
+  WorkerPool pool(num_threads > 0 ? num_threads : 1);
+  std::vector<p3hip_features> feats[2];
+  for (int h = 0; h < 2; ++h) feats[h].resize(halves[h].games.size());
+
+  auto advance_half = [&](int h, bool deliver) {
+    Half& H = halves[h];
+    pool.ParallelFor((int)H.games.size(), [&](int g) {
+      if (deliver) {
+        p3hip_result r;
+        H.eval->Get(g, r);
+        H.games[g]->DeliverResult(r);
+      }
+      H.games[g]->AdvanceToEval(&feats[h][g]);
+      H.eval->Load(g, feats[h][g]);
+    });
+  };
+  for (int h = 0; h < 2; ++h) {
+    Half* H = &halves[h];
+    H->gpu = std::thread([H] {
+      for (;;) {
+        std::unique_lock<std::mutex> l(H->mu);
+        H->cv.wait(l, [H] { return H->run_requested || H->quit; });
+        if (H->quit) return;
+        H->run_requested = false;
+        l.unlock();
+        auto t0 = std::chrono::steady_clock::now();
+        bool ok = H->eval->Run();
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        l.lock();
+        H->ok = ok;
+        H->gpu_seconds += dt;
+        ++H->runs;
+        H->run_done = true;
+        H->cv.notify_all();
+      }
+    });
+  }
+  auto request_run = [&](int h) {
+    std::lock_guard<std::mutex> l(halves[h].mu);
+    halves[h].run_done = false;
+    halves[h].run_requested = true;
+    halves[h].cv.notify_all();
+  };
+  auto wait_run = [&](int h) {
+    std::unique_lock<std::mutex> l(halves[h].mu);
+    halves[h].cv.wait(l, [&] { return halves[h].run_done; });
+    return halves[h].ok;
+  };
+  auto totals = [&](GameStats& t) {
+    t = GameStats();
+    for (auto& H : halves)
+      for (auto& g : H.games) {
+        t.moves += g->stats().moves; t.games += g->stats().games;
+        t.evals += g->stats().evals; t.black_wins += g->stats().black_wins;
+      }
+  };
+
+  int rc = 0;
+  advance_half(0, false);
+  request_run(0);
+  advance_half(1, false);
+  request_run(1);
+  GameStats base;
+  double base_gpu = 0, host_seconds = 0;
+  long base_runs = 0;
+  std::chrono::steady_clock::time_point t_start;
+  bool measuring = false;
+  long iter = 0;
+  for (;;) {
+    for (int h = 0; h < 2 && rc == 0; ++h) {
+      if (!wait_run(h)) {
+        rc = 2;
+        if (err) snprintf(err, 256, "engine run failed");
+        break;
+      }
+      auto a0 = std::chrono::steady_clock::now();
+      advance_half(h, true);
+      host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
+      request_run(h);
+    }
+    if (rc) break;
+    ++iter;
+    if (!measuring && iter >= warmup_batches) {
+      totals(base);
+      base_gpu = halves[0].gpu_seconds + halves[1].gpu_seconds;
+      base_runs = halves[0].runs + halves[1].runs;
+      host_seconds = 0;
+      t_start = std::chrono::steady_clock::now();
+      measuring = true;
+    }
+    if (measuring && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= seconds) break;
+  }
+  for (int h = 0; h < 2; ++h) wait_run(h);
+  double secs = measuring ? std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() : 0;
+  for (auto& H : halves) {
+    {
+      std::lock_guard<std::mutex> l(H.mu);
+      H.quit = true;
+    }
+    H.cv.notify_all();
+    H.gpu.join();
+  }
+  if (out) {
+    GameStats t;
+    totals(t);
+    out->seconds = secs;
+    out->positions = t.evals - base.evals;
+    out->moves = t.moves - base.moves;
+    out->games = t.games - base.games;
+    out->black_wins = t.black_wins - base.black_wins;
+    out->batches = halves[0].runs + halves[1].runs - base_runs;
+    out->gpu_seconds = halves[0].gpu_seconds + halves[1].gpu_seconds - base_gpu;
+    out->host_seconds = host_seconds;
+  }
+  return rc;
+}
+
+// Plays ONE game to the end with the NullEvaluator or the HIP engine on a single thread and
+// returns its move list (deterministic given the seed): plumbing test of BASELINE configs[0].
+int p3host_selfplay_one_game(const char* engine_lib, const char* weights, int default_n, int default_k,
+                             int max_moves, uint64_t seed, int* moves_out, int max_out, float* bscore,
+                             float* wscore, long* evals, char* err) {
+  SelfPlayConfig cfg;
+  cfg.default_n = default_n; cfg.default_k = default_k;
+  cfg.selected_n = default_n; cfg.selected_k = default_k;
+  cfg.max_moves = max_moves;
+  std::unique_ptr<Evaluator> ev;
+  if (!engine_lib || !engine_lib[0]) {
+    ev.reset(new NullEvaluator());
+  } else {
+    auto* e = new HipEvaluator();
+    ev.reset(e);
+    if (!e->Open(engine_lib, weights, 1, 0)) {
+      if (err) snprintf(err, 256, "%s", e->err.c_str());
+      return -1;
+    }
+  }
+  GameRunner g(cfg, seed);
+  p3hip_features f;
+  p3hip_result r;
+  while (g.stats().games == 0) {
+    g.AdvanceToEval(&f);
+    if (g.stats().games > 0) break;
+    ev->Load(0, f);
+    if (!ev->Run()) return -2;
+    ev->Get(0, r);
+    g.DeliverResult(r);
+  }
+  int n_out = 0;
+  const std::vector<Move>& rec = g.last_moves();
+  for (size_t i = Game::kMoveOffset; i < rec.size() && n_out < max_out; ++i)
+    moves_out[n_out++] = (MoveIdx(rec[i].loc) + 1) * (rec[i].color == kBlack ? 1 : -1);
+  if (bscore) *bscore = g.last_result().bscore;
+  if (wscore) *wscore = g.last_result().wscore;
+  if (evals) *evals = g.stats().evals;
+  return n_out;
+}
+
+}  // extern "C"

@@ -124,3 +124,50 @@ class Board:
 
     def hash(self) -> int:
         return self._L.p3host_board_hash(self._h)
+
+
+class SelfPlayStats(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("positions", C.c_long), ("moves", C.c_long),
+                ("games", C.c_long), ("black_wins", C.c_long), ("batches", C.c_long),
+                ("gpu_seconds", C.c_double), ("host_seconds", C.c_double)]
+
+
+def selfplay_run(weights: str | None, num_games: int, num_threads: int, seconds: float,
+                 default_n: int = 32, default_k: int = 5, selected_n: int = 32, selected_k: int = 5,
+                 max_moves: int = 600, warmup_batches: int = 4, seed: int = 1, device: int = 0,
+                 engine_lib: str | None = None) -> SelfPlayStats:
+    """Runs the self-play scheduler.  weights=None -> NullEvaluator (uniform policy, no GPU)."""
+    L = lib()
+    L.p3host_selfplay_run.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64,
+                                      C.POINTER(SelfPlayStats), C.c_char_p]
+    st = SelfPlayStats()
+    err = C.create_string_buffer(256)
+    if weights is None:
+        elib = None
+    else:
+        elib = (engine_lib or os.path.join(_HERE, "csrc", "libp3hip.so")).encode()
+    rc = L.p3host_selfplay_run(elib, weights.encode() if weights else None, device, num_games, num_threads,
+                               default_n, default_k, selected_n, selected_k, max_moves, seconds,
+                               warmup_batches, seed, C.byref(st), err)
+    if rc != 0:
+        raise RuntimeError(f"selfplay_run rc={rc}: {err.value.decode()}")
+    return st
+
+
+def selfplay_one_game(weights: str | None, default_n: int, default_k: int, max_moves: int, seed: int):
+    """One complete game on one thread; returns (moves, black_score, white_score, evals)."""
+    L = lib()
+    L.p3host_selfplay_one_game.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                           C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                           C.POINTER(C.c_long), C.c_char_p]
+    mv = np.zeros(1024, np.int32)
+    b, w, ev = C.c_float(), C.c_float(), C.c_long()
+    err = C.create_string_buffer(256)
+    elib = os.path.join(_HERE, "csrc", "libp3hip.so").encode() if weights else None
+    n = L.p3host_selfplay_one_game(elib, weights.encode() if weights else None, default_n, default_k,
+                                   max_moves, seed, mv.ctypes.data, len(mv), C.byref(b), C.byref(w),
+                                   C.byref(ev), err)
+    if n < 0:
+        raise RuntimeError(f"selfplay_one_game rc={n}: {err.value.decode()}")
+    return mv[:n].copy(), b.value, w.value, ev.value

@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--model", default=MODEL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-selfplay", action="store_true")
+    ap.add_argument("--selfplay-seconds", type=float, default=8.0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,6 +115,30 @@ def main():
         dist.barrier()
 
     total_flops, conv3_flops = eng.flops_per_position()
+    eng.close()
+
+    # ---- the same engine driven by the real self-play host (PCIe-inclusive; reported
+    # beside `value`, never as `value`): 2 x batch concurrent games, Gumbel n=32 ----------
+    selfplay = None
+    if not args.no_selfplay:
+        from p3achygo_amd import host_api
+        cpus = len(os.sched_getaffinity(0))
+        threads = max(2, min(16, cpus // max(world, 1)))
+        st = host_api.selfplay_run(path, 2 * args.batch, threads, args.selfplay_seconds, default_n=32,
+                                   default_k=5, selected_n=32, selected_k=5, warmup_batches=4,
+                                   seed=77 + rank, device=local_rank)
+        sp = torch.tensor([st.positions / st.seconds, st.moves / st.seconds], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(sp, op=dist.ReduceOp.SUM)
+        selfplay = {"value": float(sp[0]), "unit": "positions/s", "moves_per_s": float(sp[1]),
+                    "concurrent_games_per_gpu": 2 * args.batch, "batch": args.batch,
+                    "host_threads_per_gpu": threads, "seconds": st.seconds,
+                    "gumbel": "n=32 (default k<=5, selected k=5)", "includes": "host MCTS + PCIe + engine"}
+    eng = engine.create_engine(engine.kind_from_engine_path(path), path, args.batch, 1, device=local_rank)
+    eng.load_all(pos)
+    eng.upload()
+    eng.forward_resident(args.batch)
+    eng.sync()
     roof = None
     cpu = None
     if rank == 0:
@@ -142,7 +168,7 @@ def main():
                        "batch_per_gpu": args.batch, "parallelism": f"games sharded x{n_gpus}, no collective"},
             "full_net_tflops": pps * total_flops / 1e12,
             "conv3x3_mfma_frac_end_to_end": pps * conv3_flops / 1e12 / (PEAK_FP16_MFMA_TFLOPS * n_gpus),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "selfplay": selfplay,
         }
         print(json.dumps(out))
     eng.close()

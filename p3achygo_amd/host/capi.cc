@@ -74,3 +74,57 @@ void p3host_game_features(void* g, int color, int sym, p3hip_features* out) {
 void p3host_unapply_symmetry(int sym, p3hip_result* r) { UnapplySymmetry((Symmetry)sym, r); }
 
 }  // extern "C"
+
+// ---- scripted search (known-answer test of the Gumbel root search) ------------------------
+// Scenario of the reference's (stale) cc/mcts/__tests__/gumbel_test.cc:20-123, driven through
+// the real search instead of a hand-built tree: the prior prefers move (0,0) (logit 2) over
+// (0,1),(0,2),(0,3) (logit 1), everything else is negligible; every position after Black's
+// first move at (0,i) is worth q_i = -0.5 + i/3 to Black.  No Gumbel noise.  With n=8, k=4
+// sequential halving must visit the children 1,1,3,3 times and pick (0,3).
+#include "search.h"
+
+extern "C" int p3host_test_scripted_search(int n, int k, int* child_visits, float* child_q, int* nn_move,
+                                           int* mcts_move, int* root_n) {
+  Game game(7.5f, true);
+  NodePool pool;
+  TreeNode* root = pool.Create();
+  Probability prob(0);
+  GumbelParams p;
+  p.n = n; p.k = k; p.noise_scaling = 0.0f; p.tau = 0.0f;
+  GumbelSearch search;
+  search.Begin(&game, &pool, root, kBlack, p, &prob);
+  auto eval = [&](const Position& pos, Color to_move, p3hip_result& r) {
+    float logits[kNumMoves];
+    for (int i = 0; i < kNumMoves; ++i) logits[i] = -30.0f;
+    logits[0] = 2.0f;
+    logits[1] = logits[2] = logits[3] = 1.0f;
+    std::memcpy(r.move_logits, logits, sizeof logits);
+    SoftmaxN(logits, r.move_probs, kNumMoves);
+    std::memcpy(r.opt_move_probs, r.move_probs, sizeof r.move_probs);
+    int first = -1;   // Black's first move of the game = first non-noop entry of the move window
+    for (int i = 0; i < 5 && first < 0; ++i)
+      if (pos.last[i].color == kBlack && pos.last[i].loc.i == 0 && pos.last[i].loc.j < 4) first = pos.last[i].loc.j;
+    float q_black = first < 0 ? 0.0f : -0.5f + first / 3.0f;
+    float q = to_move == kBlack ? q_black : -q_black;
+    r.value_probs[1] = 0.5f * (1 + q);
+    r.value_probs[0] = 0.5f * (1 - q);
+    for (int i = 0; i < P3HIP_NUM_SCORE_LOGITS; ++i) r.score_probs[i] = 0.0f;
+    r.score_probs[399] = r.score_probs[400] = 0.5f;   // E[score] = 0
+    r.err2_outcome = 0.0f;
+  };
+  int guard = 0;
+  while (search.Step() == GumbelSearch::Status::kNeedEval) {
+    p3hip_result r;
+    eval(*search.eval_game(), search.eval_color(), r);
+    search.Resume(r);
+    if (++guard > 10000) return 1;
+  }
+  for (int i = 0; i < 4; ++i) {
+    child_visits[i] = root->child_visits(i);
+    child_q[i] = Q(root, i);
+  }
+  *nn_move = MoveIdx(search.result().nn_move);
+  *mcts_move = MoveIdx(search.result().mcts_move);
+  *root_n = root->n;
+  return (int)search.result().visits << 8;
+}

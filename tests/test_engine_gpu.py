@@ -145,3 +145,17 @@ def test_full_batch_properties_b12c256btl3(built, weight_files):
     for k, i in enumerate(idx):
         assert np.abs(logits[i] - raw[k][:362]).max() <= LOGIT_TOL
     eng.close()
+
+
+def test_selfplay_host_on_hip_engine(built, weight_files):
+    """The self-play host (libp3host.so) binds the engine through the C ABI with dlopen and
+    keeps two engines busy; every loaded slot is evaluated exactly once per batch."""
+    from p3achygo_amd import host_api
+    st = host_api.selfplay_run(weight_files("test_b3c128btl2"), num_games=128, num_threads=4, seconds=1.5,
+                               default_n=8, default_k=4, selected_n=8, selected_k=4, max_moves=60,
+                               warmup_batches=2, seed=5)
+    assert st.positions > 1000 and st.moves > 0 and st.games > 0
+    assert abs(st.positions - st.batches * 64) <= 128
+    mv, bs, ws, ev = host_api.selfplay_one_game(weight_files("test_b3c128btl2"), 8, 4, 80, seed=9)
+    mv2, *_ = host_api.selfplay_one_game(weight_files("test_b3c128btl2"), 8, 4, 80, seed=9)
+    assert len(mv) > 10 and np.array_equal(mv, mv2)   # deterministic on the GPU too

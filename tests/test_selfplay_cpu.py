@@ -1,0 +1,91 @@
+"""Search and self-play host on the CPU with the NullEvaluator (uniform policy — the
+reference's NullEngine, cc/mcts/__tests__/search_test.cc:49-65) and a scripted evaluator."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def host(built):
+    from p3achygo_amd import host_api
+    return host_api
+
+
+def test_gumbel_known_answer(host):
+    """Scenario of cc/mcts/__tests__/gumbel_test.cc:74-123 (n=8, k=4, no noise): sequential
+    halving spends exactly n visits, splits them 1/1/3/3, keeps the best two after round 1
+    and picks (0,3); the network's own move is (0,0); child Qs reproduce the scripted values
+    (plus the small score-utility term, |.| < 0.02)."""
+    L = host.lib()
+    cv = (C.c_int * 4)()
+    cq = (C.c_float * 4)()
+    nn, mc, rn = C.c_int(), C.c_int(), C.c_int()
+    rc = L.p3host_test_scripted_search(8, 4, cv, cq, C.byref(nn), C.byref(mc), C.byref(rn))
+    assert rc >> 8 == 8                       # visits spent == n
+    assert list(cv) == [1, 1, 3, 3]
+    assert nn.value == 0 and mc.value == 3
+    assert rn.value == 8                      # root n = sum of child visits (gumbel.cc:550-554)
+    for i in range(4):
+        assert abs(cq[i] - (-0.5 + i / 3.0)) < 0.02
+
+
+@pytest.mark.parametrize("n,k,expect,best", [(32, 4, 32, 3), (16, 2, 16, 1), (128, 8, 126, 3), (32, 5, 31, 3)])
+def test_gumbel_visit_budget(host, n, k, expect, best):
+    """Visits spent = sum over halving rounds of round(n / (rounds * k_r)) * k_r
+    (gumbel.cc:388-473); the budget invariant the reference checks in search_test.cc:130-222."""
+    L = host.lib()
+    cv = (C.c_int * 4)()
+    cq = (C.c_float * 4)()
+    nn, mc, rn = C.c_int(), C.c_int(), C.c_int()
+    rc = L.p3host_test_scripted_search(n, k, cv, cq, C.byref(nn), C.byref(mc), C.byref(rn))
+    rounds = max(int(np.log2(k)), 1)
+    spent, kk = 0, k
+    while kk > 1:
+        spent += int(np.floor(n / (rounds * kk) + 0.5)) * kk
+        kk //= 2
+    assert rc >> 8 == spent == expect
+    assert mc.value == best                   # best-valued move among the top-k by prior
+
+
+def _replay(host, moves):
+    b = host.Board()
+    passes = 0
+    for m in moves:
+        col = 1 if m > 0 else -1
+        idx = abs(int(m)) - 1
+        if idx == 361:
+            b.pass_(col)
+            passes += 1
+        else:
+            assert b.play(idx // 19, idx % 19, col), "illegal move in recorded game"
+            passes = 0
+    return b
+
+
+def test_one_game_deterministic_and_legal(host):
+    """BASELINE configs[0] plumbing case (1 thread, n=8 k=4): a whole game is reproducible
+    from its seed, alternates colours, contains only legal moves and ends by two passes or the
+    move cap; the recorded score equals a fresh rules-engine replay."""
+    mv, bs, ws, ev = host.selfplay_one_game(None, 8, 4, 120, seed=42)
+    mv2, bs2, ws2, ev2 = host.selfplay_one_game(None, 8, 4, 120, seed=42)
+    assert np.array_equal(mv, mv2) and (bs, ws, ev) == (bs2, ws2, ev2)
+    mv3, *_ = host.selfplay_one_game(None, 8, 4, 120, seed=43)
+    assert not np.array_equal(mv, mv3)
+    assert len(mv) <= 120 and ev > len(mv)
+    assert all((m > 0) == (i % 2 == 0) for i, m in enumerate(mv))
+    b = _replay(host, mv)
+    assert len(mv) == 120 or b.is_game_over()
+    rb, rw, _ = b.scores()
+    assert (rb, rw) == (bs, ws)
+
+
+def test_scheduler_with_null_engine(host):
+    """The double-buffered scheduler drives many games on several threads; every evaluation
+    is counted once and all games make progress."""
+    st = host.selfplay_run(None, num_games=64, num_threads=4, seconds=1.0, default_n=8, default_k=4,
+                           selected_n=8, selected_k=4, max_moves=40, warmup_batches=1, seed=3)
+    assert st.positions > 64 and st.moves > 0 and st.batches > 2
+    assert st.games > 0                       # 40-move cap: games finish and restart
+    # one batch = one evaluation per game of the half
+    assert abs(st.positions - st.batches * 32) <= 64

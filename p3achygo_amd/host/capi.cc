@@ -83,6 +83,10 @@ void p3host_unapply_symmetry(int sym, p3hip_result* r) { UnapplySymmetry((Symmet
 // sequential halving must visit the children 1,1,3,3 times and pick (0,3).
 #include "search.h"
 
+extern "C" void p3host_softmax(const float* in, float* out, int n) { SoftmaxN(in, out, n); }
+
+// k > 0: Gumbel root search (n, k); k == 0: SearchRootPuct with n playouts (self-play's
+// fast-move parameters).
 extern "C" int p3host_test_scripted_search(int n, int k, int* child_visits, float* child_q, int* nn_move,
                                            int* mcts_move, int* root_n) {
   Game game(7.5f, true);
@@ -92,7 +96,13 @@ extern "C" int p3host_test_scripted_search(int n, int k, int* child_visits, floa
   GumbelParams p;
   p.n = n; p.k = k; p.noise_scaling = 0.0f; p.tau = 0.0f;
   GumbelSearch search;
-  search.Begin(&game, &pool, root, kBlack, p, &prob);
+  if (k > 0) {
+    search.Begin(&game, &pool, root, kBlack, p, &prob);
+  } else {
+    PuctParams pp;
+    pp.c_puct = 1.05f; pp.c_puct_visit_scaling = 0.28f; pp.root_fpu = 0.05f;
+    search.BeginPuct(&game, &pool, root, kBlack, n, pp, 0.5f, &prob);
+  }
   auto eval = [&](const Position& pos, Color to_move, p3hip_result& r) {
     float logits[kNumMoves];
     for (int i = 0; i < kNumMoves; ++i) logits[i] = -30.0f;

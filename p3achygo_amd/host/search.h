@@ -193,9 +193,11 @@ struct PuctParams {
   float c_puct = 1.0f, c_puct_visit_scaling = 0.45f;
   bool enable_var_scaling = false;
   int var_scale_prior_visits = 0;
+  float root_fpu = kDefaultFPU;
 };
 
-inline int PuctTopMove(const TreeNode* node, const Board& board, Color color, const PuctParams& pp) {
+inline int PuctTopMove(const TreeNode* node, const Board& board, Color color, const PuctParams& pp,
+                       bool is_root = false) {
   const int n = node->n;
   const float v = node->v;
   int cv[kNumMoves] = {};
@@ -213,7 +215,7 @@ inline int PuctTopMove(const TreeNode* node, const Board& board, Color color, co
   float p_explored = 0;
   for (const ChildEdge& e : node->children)
     if (e.visits > 0) p_explored += node->move_probs[e.action];
-  const float v_fpu = v - kDefaultFPU * std::sqrt(p_explored);
+  const float v_fpu = v - (is_root ? pp.root_fpu : kDefaultFPU) * std::sqrt(p_explored);
   const float c_puct = pp.c_puct + pp.c_puct_visit_scaling * std::log((n + 500.0f) / 500.0f);
   float total_n = 1;
   for (const ChildEdge& e : node->children) total_n += e.visits;
@@ -266,9 +268,23 @@ class GumbelSearch {
   void Begin(Game* game, NodePool* pool, TreeNode* root, Color color, const GumbelParams& p,
              Probability* prob) {
     game_ = game; pool_ = pool; root_ = root; color_ = color; p_ = p; prob_ = prob;
+    puct_root_ = false;
     root_pos_ = Position(*game);
     state_ = root->evaluated ? State::kPrepare : State::kRootEval;
     res_ = GumbelResult();
+  }
+
+  // SearchRootPuct (gumbel.cc:563-666) with PuctRootSelectionPolicy::kVisitCountSample as
+  // self-play uses it for fast moves (self_play_thread.cc:600-611): n PUCT playouts from the
+  // root, improved policy = normalised new visit counts, move = argmax of them when tau > 0
+  // (the branch is inverted in the reference).
+  void BeginPuct(Game* game, NodePool* pool, TreeNode* root, Color color, int n, const PuctParams& pp,
+                 float tau, Probability* prob) {
+    GumbelParams gp;
+    gp.n = n; gp.tau = tau;
+    Begin(game, pool, root, color, gp, prob);
+    puct_root_ = true;
+    puct_pp_ = pp;
   }
 
   // Runs until an evaluation is needed (then eval_game()/eval_color() name the position) or
@@ -286,10 +302,20 @@ class GumbelSearch {
           state_ = State::kPrepare;
           break;
         case State::kPrepare:
-          if (Prepare()) { state_ = State::kDone; return Status::kDone; }
+          if (puct_root_) {
+            PreparePuct();
+          } else if (Prepare()) {
+            state_ = State::kDone;
+            return Status::kDone;
+          }
           state_ = State::kNextVisit;
           break;
         case State::kNextVisit:
+          if (puct_root_) {
+            if (visits_spent_ >= (uint32_t)p_.n) { FinishPuct(); state_ = State::kDone; return Status::kDone; }
+            if (StartVisitPuct()) return Status::kNeedEval;
+            break;
+          }
           if (!AdvanceLoop()) { Finish(); state_ = State::kDone; return Status::kDone; }
           if (StartVisit()) return Status::kNeedEval;   // else visit completed synchronously
           break;
@@ -430,6 +456,66 @@ class GumbelSearch {
     return false;
   }
 
+  // ---- PUCT at the root ---------------------------------------------------------------
+  void PreparePuct() {
+    pre_visits_.clear();
+    for (const ChildEdge& e : root_->children) pre_visits_.push_back({e.action, e.visits});
+    visits_spent_ = 0;
+    int amax = 0;
+    for (int i = 1; i < kNumMoves; ++i)
+      if (root_->move_logits[i] > root_->move_logits[amax]) amax = i;
+    res_.nn_move = MoveLoc(amax);
+  }
+  bool StartVisitPuct() {
+    search_game_ = root_pos_;
+    path_.clear();
+    path_.push_back(PathEntry{-1, root_});
+    Color c = color_;
+    bool first = true;
+    while (path_.back().node->evaluated && !path_.back().node->is_terminal && !search_game_.IsGameOver()) {
+      TreeNode* node = path_.back().node;
+      int a = PuctTopMove(node, search_game_.board, c, puct_pp_, first);
+      first = false;
+      if (a < 0) a = kPassEncoding;
+      search_game_.PlayMove(MoveLoc(a), c);
+      TreeNode* nx = GetOrCreateChild(node, a);
+      path_.back().action = a;
+      path_.push_back(PathEntry{-1, nx});
+      c = Opp(c);
+    }
+    leaf_color_ = c;
+    TreeNode* leaf = path_.back().node;
+    if (!leaf->evaluated && !search_game_.IsGameOver()) {
+      eval_game_ = &search_game_;
+      eval_color_ = c;
+      state_ = State::kLeafEvalWait;
+      return true;
+    }
+    if (!leaf->evaluated) leaf->evaluated = true;
+    CompleteVisit();
+    return false;
+  }
+  void FinishPuct() {
+    float counts[kNumMoves] = {};
+    float total = 0;
+    for (const ChildEdge& e : root_->children) {
+      int pre = 0;
+      for (auto& pv : pre_visits_)
+        if (pv.first == e.action) pre = pv.second;
+      counts[e.action] = (float)(e.visits - pre);
+      total += counts[e.action];
+    }
+    int amax = 0;
+    for (int a = 0; a < kNumMoves; ++a) {
+      res_.pi_improved[a] = total > 0 ? counts[a] / total : 0.0f;
+      if (counts[a] > counts[amax]) amax = a;
+    }
+    int mv = p_.tau > 0.0f ? amax : SampleFromPolicy(res_.pi_improved, p_.tau);
+    res_.mcts_move = MoveLoc(mv);
+    res_.visits = visits_spent_;
+    res_.kld = 0;
+  }
+
   void CompleteVisit() {
     TreeNode* leaf = path_.back().node;
     if (search_game_.IsGameOver() && !leaf->is_terminal) {
@@ -438,8 +524,9 @@ class GumbelSearch {
       leaf->evaluated = true;
     }
     Backward();
-    root_->edge(gm_[cand_].enc)->visits += 1;
     ++visits_spent_;
+    if (puct_root_) return;   // the root is part of the path and was updated by Backward
+    root_->edge(gm_[cand_].enc)->visits += 1;
     ++cand_;
   }
 
@@ -574,6 +661,9 @@ class GumbelSearch {
   uint32_t visits_spent_ = 0;
   bool round_open_ = false;
   Position root_pos_, search_game_;
+  bool puct_root_ = false;
+  PuctParams puct_pp_;
+  std::vector<std::pair<int, int>> pre_visits_;
   std::vector<PathEntry> path_;
   Color leaf_color_ = kBlack;
   const Position* eval_game_ = nullptr;

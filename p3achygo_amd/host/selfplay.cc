@@ -6,8 +6,8 @@
 // otherwise a fast search with per-game k and noise scaling), temperature schedule, Gumbel
 // root search, tree reuse + Reap, pass-alive refresh at moves 200/250/.../400, max_moves,
 // final scoring.  Not restated this round: GoExploit/regret reuse buffer,
-// ForkManager, opening book, handicap games, sel_mult, bias cache, the PUCT fast-search
-// variant, resignation bookkeeping, recorders.
+// ForkManager, opening book, handicap games, sel_mult, bias cache, down-bad visit annealing,
+// recorders.
 //
 // Scheduling is new (the reference runs one OS thread per game and a 400 us batching
 // timeout, nn_interface.cc:279-404): games are resumable state machines (search.h) split in
@@ -107,6 +107,8 @@ struct SelfPlayConfig {       // SPConfig, cc/selfplay/self_play_thread.h:38-61 
   int nonroot_var_scale_prior_visits = 10;
   float komi = 7.5f;
   bool raw_policy_opening = true;
+  int cache_entries_per_game = 64;   // 0 disables the evaluation cache
+  bool enable_puct_fast_search = true;
 };
 
 constexpr int kMaxNumRawPolicyMoves = 30;              // self_play_thread.cc:45
@@ -114,18 +116,69 @@ constexpr float kMoveSelectedForTrainingProb = 0.25f;  // :62
 constexpr int kComputePAMoveNums[] = {200, 250, 300, 350, 400};   // :56
 
 struct GameStats {
-  long moves = 0, games = 0, evals = 0, black_wins = 0;
+  long moves = 0, games = 0, evals = 0, black_wins = 0, cache_hits = 0;
+};
+
+// Per-game evaluation cache: the reference keeps one LRU per game thread keyed by
+// NNKey = (colour, board hash, last `num_cache_last_moves` moves, komi)
+// (cc/nn/nn_interface.h:206-228, nn_interface.cc:92-118; self-play sets 1 last move,
+// selfplay/main.cc:177).  Results are stored un-symmetrised, as the reference does.
+class EvalCache {
+ public:
+  explicit EvalCache(int capacity) : cap_(capacity) {}
+  struct Key {
+    uint64_t hash;
+    int last_i, last_j;
+    float komi;
+    Color color;
+    bool operator==(const Key& o) const {
+      return hash == o.hash && last_i == o.last_i && last_j == o.last_j && komi == o.komi && color == o.color;
+    }
+  };
+  static Key MakeKey(const Position& pos, Color c) {
+    return Key{pos.board.hash(), pos.last[4].loc.i, pos.last[4].loc.j, pos.komi(), c};
+  }
+  const p3hip_result* Find(const Key& k) {
+    for (auto& e : entries_)
+      if (e.key == k) { e.stamp = ++clock_; return &e.result; }
+    return nullptr;
+  }
+  void Insert(const Key& k, const p3hip_result& r) {
+    if (cap_ <= 0) return;
+    if ((int)entries_.size() < cap_) {
+      entries_.push_back(Entry{k, ++clock_, r});
+      return;
+    }
+    size_t lru = 0;
+    for (size_t i = 1; i < entries_.size(); ++i)
+      if (entries_[i].stamp < entries_[lru].stamp) lru = i;
+    entries_[lru] = Entry{k, ++clock_, r};
+  }
+  void Clear() { entries_.clear(); }
+
+ private:
+  struct Entry { Key key; uint64_t stamp; p3hip_result result; };
+  int cap_;
+  uint64_t clock_ = 0;
+  std::vector<Entry> entries_;
 };
 
 class GameRunner {
  public:
-  GameRunner(const SelfPlayConfig& cfg, uint64_t seed) : cfg_(cfg), prob_(seed), seed_(seed) { NewGame(); }
+  GameRunner(const SelfPlayConfig& cfg, uint64_t seed)
+      : cfg_(cfg), prob_(seed), seed_(seed), cache_(cfg.cache_entries_per_game) { NewGame(); }
 
   // Advances this game until it needs a network evaluation; writes the features of the
   // position to evaluate into *f.
   void AdvanceToEval(p3hip_features* f) {
     for (;;) {
       if (search_.Step() == GumbelSearch::Status::kNeedEval) {
+        pending_key_ = EvalCache::MakeKey(*search_.eval_game(), search_.eval_color());
+        if (const p3hip_result* hit = cache_.Find(pending_key_)) {   // nn_interface.cc:112-118
+          ++stats_.cache_hits;
+          search_.Resume(*hit);
+          continue;
+        }
         sym_ = RandomSymmetry(prob_.prng());   // nn_interface.cc:123
         FillFeatures(*search_.eval_game(), search_.eval_color(), sym_, f);
         ++stats_.evals;
@@ -136,6 +189,7 @@ class GameRunner {
   }
   void DeliverResult(p3hip_result& r) {
     UnapplySymmetry(sym_, &r);   // nn_interface.h:263-288
+    cache_.Insert(pending_key_, r);   // nn_interface.cc:130
     search_.Resume(r);
   }
   const GameStats& stats() const { return stats_; }
@@ -152,14 +206,15 @@ class GameRunner {
     // per-game draws, self_play_thread.cc:364-368,413-423
     const int max_raw = kMaxNumRawPolicyMoves;
     num_moves_raw_policy_ = cfg_.raw_policy_opening ? RandRange(prob_.prng(), 0, max_raw) : 0;
-    (void)prob_.Uniform();   // use_puct_fast_search draw (variant not restated; keeps the stream aligned)
+    use_puct_fast_search_ = prob_.Uniform() < 0.25f && cfg_.enable_puct_fast_search;   // kPuctFastSearchProb, :74
     fast_move_noise_scaling_ = prob_.Uniform() / 1.4f;
     {
       int num_rounds = (int)std::log2((double)cfg_.default_k);
       int min_k = 1 << num_rounds;
       fast_move_gumbel_k_ = RandRange(prob_.prng(), min_k, cfg_.default_k + 1);
     }
-    (void)prob_.Uniform();   // fast_move_root_fpu draw
+    fast_move_root_fpu_ = prob_.Uniform() * 0.1f;   // :424
+    cache_.Clear();
     BeginSearch();
   }
 
@@ -181,6 +236,14 @@ class GameRunner {
       const int non_sample = game_->num_moves() - num_moves_raw_policy_;
       const float lambda = std::log(2.0f) / 19;
       p.tau = std::min(std::max(0.8f * std::exp(-lambda * non_sample), 0.2f), 0.8f);
+    }
+    if (!selected && !sampling_raw_policy && use_puct_fast_search_) {   // self_play_thread.cc:585-611
+      PuctParams pp;
+      pp.c_puct = 1.05f;
+      pp.c_puct_visit_scaling = 0.28f;
+      pp.root_fpu = fast_move_root_fpu_;
+      search_.BeginPuct(game_.get(), &pool_, root_, color_, p.n, pp, p.tau, &prob_);
+      return;
     }
     search_.Begin(game_.get(), &pool_, root_, color_, p, &prob_);
   }
@@ -223,7 +286,10 @@ class GameRunner {
   GumbelSearch search_;
   Symmetry sym_ = kIdentity;
   int num_moves_raw_policy_ = 0, fast_move_gumbel_k_ = 4;
-  float fast_move_noise_scaling_ = 1.0f;
+  float fast_move_noise_scaling_ = 1.0f, fast_move_root_fpu_ = 0.0f;
+  bool use_puct_fast_search_ = false;
+  EvalCache cache_;
+  EvalCache::Key pending_key_{};
   GameStats stats_;
   Game::Result last_result_;
   std::vector<Move> last_moves_;
@@ -318,6 +384,7 @@ struct p3host_selfplay_stats {
   long batches;              // engine runs
   double gpu_seconds;        // time spent inside Evaluator::Run, summed over both halves
   double host_seconds;       // time spent advancing games (both halves, wall)
+  long cache_hits;           // evaluations served by the per-game cache (not in `positions`)
 };
 
 // Runs self-play for about `seconds` (after `warmup_batches` unmeasured batches per half).
@@ -406,6 +473,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
       for (auto& g : H.games) {
         t.moves += g->stats().moves; t.games += g->stats().games;
         t.evals += g->stats().evals; t.black_wins += g->stats().black_wins;
+        t.cache_hits += g->stats().cache_hits;
       }
   };
 
@@ -465,6 +533,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     out->batches = halves[0].runs + halves[1].runs - base_runs;
     out->gpu_seconds = halves[0].gpu_seconds + halves[1].gpu_seconds - base_gpu;
     out->host_seconds = host_seconds;
+    out->cache_hits = t.cache_hits - base.cache_hits;
   }
   return rc;
 }

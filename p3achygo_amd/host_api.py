@@ -129,7 +129,7 @@ class Board:
 class SelfPlayStats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("positions", C.c_long), ("moves", C.c_long),
                 ("games", C.c_long), ("black_wins", C.c_long), ("batches", C.c_long),
-                ("gpu_seconds", C.c_double), ("host_seconds", C.c_double)]
+                ("gpu_seconds", C.c_double), ("host_seconds", C.c_double), ("cache_hits", C.c_long)]
 
 
 def selfplay_run(weights: str | None, num_games: int, num_threads: int, seconds: float,

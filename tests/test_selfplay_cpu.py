@@ -83,9 +83,53 @@ def test_one_game_deterministic_and_legal(host):
 def test_scheduler_with_null_engine(host):
     """The double-buffered scheduler drives many games on several threads; every evaluation
     is counted once and all games make progress."""
-    st = host.selfplay_run(None, num_games=64, num_threads=4, seconds=1.0, default_n=8, default_k=4,
-                           selected_n=8, selected_k=4, max_moves=40, warmup_batches=1, seed=3)
+    st = host.selfplay_run(None, num_games=64, num_threads=4, seconds=2.5, default_n=8, default_k=4,
+                           selected_n=8, selected_k=4, max_moves=16, warmup_batches=1, seed=3)
     assert st.positions > 64 and st.moves > 0 and st.batches > 2
-    assert st.games > 0                       # 40-move cap: games finish and restart
+    assert st.games > 0                       # 16-move cap: games finish and restart
     # one batch = one evaluation per game of the half
     assert abs(st.positions - st.batches * 32) <= 64
+
+
+def test_puct_root_search(host):
+    """SearchRootPuct (gumbel.cc:563-666) on the scripted position: exactly n playouts, the
+    root's visit count grows by n (it is on the backup path, unlike the Gumbel root), the
+    move is the arg-max of the new visit counts, and with enough playouts PUCT concentrates
+    on the best-valued move (0,3)."""
+    L = host.lib()
+    cv = (C.c_int * 4)()
+    cq = (C.c_float * 4)()
+    nn, mc, rn = C.c_int(), C.c_int(), C.c_int()
+    for n in (8, 64):
+        rc = L.p3host_test_scripted_search(n, 0, cv, cq, C.byref(nn), C.byref(mc), C.byref(rn))
+        assert rc >> 8 == n
+        assert rn.value == 1 + n              # EvaluateRoot sets n = 1, then one per playout
+        assert sum(cv) <= n and nn.value == 0
+        assert mc.value == int(np.argmax(list(cv)))
+    assert mc.value == 3 and cv[3] > cv[0]
+
+
+def test_softmax_known_answers(host):
+    """core::SoftmaxV known answers of cc/core/__tests__/vmath_test.cc:42-107."""
+    L = host.lib()
+    L.p3host_softmax.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    cases = [
+        ([1.0, 1.5, 2.0], [0.18632372, 0.30719589, 0.50648039]),
+        ([5.2, 1.3, -4.4, 4.5, -3.0, 7.2, 2.1, -4.0],
+         [1.11714669e-01, 2.26131844e-03, 7.56629338e-06, 5.54758628e-02, 3.06828327e-05, 8.25465956e-01,
+          5.03265673e-03, 1.12875833e-05]),
+        ([5.2, 1.3, -4.4, 4.5, -3.0, 7.2, 2.1, -4.0, 9.8, 4.6],
+         [9.17561645e-03, 1.85732016e-04, 6.21452908e-07, 4.55647628e-03, 2.52011581e-06, 6.77991447e-02,
+          4.13354202e-04, 9.27098797e-07, 9.12829923e-01, 5.03568507e-03]),
+        ([-149.944, -157.025, -158.732, -158.947, -160.693, -161.818, -161.623],
+         [9.9884784e-01, 8.3996827e-04, 1.5237786e-04, 1.2289763e-04, 2.1442285e-05, 6.9612906e-06,
+          8.4600651e-06]),
+        ([1.0, 2.0, 3.0, 4.0], [0.03205860, 0.08714432, 0.23688282, 0.64391426]),
+        ([2.0, 2.0, 2.0, 2.0], [0.25, 0.25, 0.25, 0.25]),
+        ([100.0, 0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]),
+    ]
+    for x, want in cases:
+        a = np.array(x, np.float32)
+        out = np.zeros_like(a)
+        L.p3host_softmax(a.ctypes.data, out.ctypes.data, len(a))
+        assert np.allclose(out, want, rtol=2e-5, atol=1e-9), x

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "features.h"
+#include "recorder.h"
 #include "search.h"
 
 namespace p3 {
@@ -109,6 +110,7 @@ struct SelfPlayConfig {       // SPConfig, cc/selfplay/self_play_thread.h:38-61 
   bool raw_policy_opening = true;
   int cache_entries_per_game = 64;   // 0 disables the evaluation cache
   bool enable_puct_fast_search = true;
+  SgfRecorder* sgf = nullptr;        // optional: finished games are serialized here
 };
 
 constexpr int kMaxNumRawPolicyMoves = 30;              // self_play_thread.cc:45
@@ -266,6 +268,7 @@ class GameRunner {
       if (game_->result().winner == kBlack) ++stats_.black_wins;
       last_result_ = game_->result();
       last_moves_ = game_->moves();
+      if (cfg_.sgf) cfg_.sgf->RecordGame(SgfGameString(*game_, "p3achygo", "p3achygo"));   // game_recorder.cc:20,108
       NewGame();
       return;
     }
@@ -375,7 +378,36 @@ struct Half {
 
 using namespace p3;
 
+namespace {
+std::string g_rec_dir, g_rec_worker = "0";
+int g_rec_gen = 0, g_rec_flush_interval = 128;   // --flush_interval, selfplay/main.cc:35
+}
+
 extern "C" {
+
+// Enables SGF recording for subsequent p3host_selfplay_run calls (dir == "" disables).
+void p3host_selfplay_set_recorder(const char* dir, int gen, const char* worker_id, int flush_interval) {
+  g_rec_dir = dir ? dir : "";
+  g_rec_gen = gen;
+  g_rec_worker = worker_id ? worker_id : "0";
+  g_rec_flush_interval = flush_interval > 0 ? flush_interval : 128;
+}
+
+// Serializes a move list (encoded as in p3host_selfplay_one_game) the way the recorder does.
+int p3host_sgf_from_moves(const int* moves, int n, float komi, int write_result, const char* b_name,
+                          const char* w_name, char* out, int cap) {
+  Game g(komi, true);
+  for (int i = 0; i < n; ++i) {
+    Color c = moves[i] > 0 ? kBlack : kWhite;
+    int idx = (moves[i] > 0 ? moves[i] : -moves[i]) - 1;
+    g.PlayMove(MoveLoc(idx), c);
+  }
+  if (write_result) g.WriteResult();
+  std::string s = SgfGameString(g, b_name, w_name);
+  if ((int)s.size() + 1 > cap) return -1;
+  std::memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
 
 struct p3host_selfplay_stats {
   double seconds;            // wall time of the measured region
@@ -399,6 +431,11 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   cfg.default_n = default_n; cfg.default_k = default_k;
   cfg.selected_n = selected_n; cfg.selected_k = selected_k;
   cfg.max_moves = max_moves;
+  std::unique_ptr<SgfRecorder> sgf;
+  if (!g_rec_dir.empty()) {
+    sgf.reset(new SgfRecorder(g_rec_dir, g_rec_gen, g_rec_worker));
+    cfg.sgf = sgf.get();
+  }
   Half halves[2];
   const bool use_null = !engine_lib || !engine_lib[0];
   for (int h = 0; h < 2; ++h) {
@@ -501,6 +538,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
       request_run(h);
     }
     if (rc) break;
+    if (sgf && sgf->buffered() >= g_rec_flush_interval) sgf->Flush();
     ++iter;
     if (!measuring && iter >= warmup_batches) {
       totals(base);
@@ -522,6 +560,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     H.cv.notify_all();
     H.gpu.join();
   }
+  if (sgf) sgf->Flush();
   if (out) {
     GameStats t;
     totals(t);

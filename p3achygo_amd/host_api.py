@@ -171,3 +171,23 @@ def selfplay_one_game(weights: str | None, default_n: int, default_k: int, max_m
     if n < 0:
         raise RuntimeError(f"selfplay_one_game rc={n}: {err.value.decode()}")
     return mv[:n].copy(), b.value, w.value, ev.value
+
+
+def set_recorder(directory: str, gen: int = 0, worker_id: str = "0", flush_interval: int = 128) -> None:
+    """SGF recording for subsequent selfplay_run calls ('' disables)."""
+    L = lib()
+    L.p3host_selfplay_set_recorder.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    L.p3host_selfplay_set_recorder(directory.encode(), gen, worker_id.encode(), flush_interval)
+
+
+def sgf_from_moves(moves, komi: float = 7.5, write_result: bool = False, b_name: str = "testB",
+                   w_name: str = "testW") -> str:
+    L = lib()
+    L.p3host_sgf_from_moves.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_char_p, C.c_char_p,
+                                        C.c_char_p, C.c_int]
+    mv = np.asarray(moves, np.int32)
+    out = C.create_string_buffer(1 << 16)
+    n = L.p3host_sgf_from_moves(mv.ctypes.data if len(mv) else None, len(mv), komi, int(write_result),
+                                b_name.encode(), w_name.encode(), out, len(out))
+    assert n >= 0
+    return out.value.decode()

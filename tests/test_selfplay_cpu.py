@@ -133,3 +133,52 @@ def test_softmax_known_answers(host):
         out = np.zeros_like(a)
         L.p3host_softmax(a.ctypes.data, out.ctypes.data, len(a))
         assert np.allclose(out, want, rtol=2e-5, atol=1e-9), x
+
+
+def _mv(color, i, j):
+    return (i * 19 + j + 1) * color
+
+
+def test_sgf_golden_strings(host):
+    """Known answers of cc/sgf/__tests__/sgf_serializer_test.cc:47-112 (minus the trailing
+    newline, which the recorder appends: sgf_recorder.cc:282-285).  Coordinates are emitted
+    row letter first (sgf_serializer.cc:27-32)."""
+    assert host.sgf_from_moves([]) == "(;FF[4]GM[1]KM[7.5]RE[?]PB[testB]PW[testW])"
+    assert host.sgf_from_moves([], write_result=True) == "(;FF[4]GM[1]KM[7.5]RE[W+7.5]PB[testB]PW[testW])"
+    moves = [_mv(1, 0, 0), _mv(-1, 1, 0), _mv(1, 0, 1), _mv(-1, 1, 1)]
+    assert host.sgf_from_moves(moves) == "(;FF[4]GM[1]KM[7.5]RE[?]PB[testB]PW[testW];B[aa];W[ba];B[ab];W[bb])"
+    white_win = [_mv(1, 0, 2), _mv(-1, 0, 3), _mv(1, 1, 2), _mv(-1, 1, 3), _mv(1, 2, 2), _mv(-1, 2, 4),
+                 _mv(1, 2, 0), _mv(-1, 1, 5), _mv(1, 2, 1), _mv(-1, 0, 5)]
+    assert host.sgf_from_moves(white_win, write_result=True) == (
+        "(;FF[4]GM[1]KM[7.5]RE[W+5.5]PB[testB]PW[testW];B[ac];W[ad];B[bc];W[bd];B[cc];W[ce];B[ca];W[bf];B[cb];W[af])")
+    black_win = [_mv(1, 0, 2), _mv(1, 1, 2), _mv(1, 2, 2), _mv(1, 2, 0), _mv(1, 2, 1), _mv(-1, 2, 3)]
+    assert host.sgf_from_moves(black_win, write_result=True) == (
+        "(;FF[4]GM[1]KM[7.5]RE[B+0.5]PB[testB]PW[testW];B[ac];B[bc];B[cc];B[ca];B[cb];W[cd])")
+    assert host.sgf_from_moves([_mv(1, 3, 3), 362 * -1]) .endswith(";B[dd];W[])")   # pass = empty value
+
+
+def test_sgf_recorder_files(host, tmp_path):
+    """Batch files follow cc/data/filename_format.h:27-31: gen%03d_b%03d_g%03d_%s.sgf with one
+    game per line and a matching .done file (sgf_recorder.cc:266-326)."""
+    import os
+    import re
+    host.set_recorder(str(tmp_path), gen=7, worker_id="w3", flush_interval=4)
+    try:
+        st = host.selfplay_run(None, num_games=16, num_threads=2, seconds=1.5, default_n=4, default_k=2,
+                               selected_n=4, selected_k=2, max_moves=12, warmup_batches=0, seed=11)
+    finally:
+        host.set_recorder("")
+    files = sorted(os.listdir(tmp_path))
+    sgfs = [f for f in files if f.endswith(".sgf")]
+    assert sgfs and all(re.fullmatch(r"gen007_b\d{3}_g\d{3}_w3\.sgf", f) for f in sgfs)
+    total = 0
+    for f in sgfs:
+        assert f[:-4] + ".done" in files
+        lines = open(os.path.join(tmp_path, f)).read().split("\n")
+        assert lines[-1] == ""
+        n_games = int(re.search(r"_g(\d{3})_", f).group(1))
+        assert len(lines) - 1 == n_games
+        for ln in lines[:-1]:
+            assert ln.startswith("(;FF[4]GM[1]KM[7.5]RE[") and "PB[p3achygo]PW[p3achygo]" in ln and ln.endswith(")")
+        total += n_games
+    assert total >= st.games

@@ -10,7 +10,7 @@ resident in HBM when the timed region starts.  Games shard embarrassingly across
 (one engine + one HIP stream per device, no collective on the data path), so scaling is
 weak: every rank evaluates its own 1024 positions.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel k_block: 3x3-conv FLOPs per
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel k_block: conv FLOPs (3x3s + 1x1 reduce/expand) per
 launch / HIP-event time, against the 2.5 PFLOP/s dense fp16 MFMA peak) and `cpu_baseline`
 (the CPU fp32 oracle timed on this box's host cores over a bounded sample).
 """

@@ -87,7 +87,6 @@ typedef struct p3hip_engine p3hip_engine;
 #define P3HIP_FLAG_NO_GRAPH 1u      /* launch kernels eagerly instead of replaying a hipGraph */
 #define P3HIP_FLAG_RUN_ALL_SLOTS 2u /* always run the full static batch (TRT behaviour,
                                        trt_engine.cc:238-304); default compacts to loaded slots */
-#define P3HIP_FLAG_LAYERWISE 4u     /* use one kernel per conv layer instead of fused blocks */
 
 /* Creates an engine from a `.p3w` weight file (see p3achygo_amd/netspec.py) for a static
  * batch of `batch_size` slots on HIP device `device_ordinal`.  `version` is the model
@@ -129,7 +128,8 @@ int p3hip_sync(p3hip_engine* e);
 int p3hip_get_raw(p3hip_engine* e, int slot, float* out);
 /* Times `iters` launches of the dominant trunk kernel alone with HIP events on the
  * engine's stream; returns average milliseconds per launch (<0 on error) and writes the
- * number of positions one launch processed and its 3x3-conv FLOPs. */
+ * algorithmic FLOPs of the convs one launch executes (inner 3x3s + 1x1 reduce/expand,
+ * unpadded 361 points). */
 double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
                                double* flops_per_launch, const char** kernel_name);
 /* Diagnostic build of the fused block kernel with in-kernel s_memtime stamps at phase

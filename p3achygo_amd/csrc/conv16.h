@@ -1,0 +1,292 @@
+// conv16.h — the conv segment and its epilogues on v_mfma_f32_16x16x32_f16.
+//
+// Same ownership as conv_core.h's 32x32x16 path (a wave owns 64 output channels x 96
+// padded board rows, weights = A operand, activations = B operand, same LDS images and the
+// same packed weight stream: one k32 step is two consecutive k16 blocks), but the wave's
+// tile is cut into 4 x 6 tiles of 16 x 16 with K = 32 per instruction.  Per k32 step a wave
+// issues 24 MFMAs (16 cycles each) and 10 ds_read_b128 — the same LDS traffic per FLOP as
+// the 32x32x16 form — and the chip sustains a higher clock on this instruction mix
+// (MI355X_MICROARCH.md, "16x16x32 ... 1.12-1.15x the FLOP/s at equal cycles per FLOP").
+//
+// Lane l = (n = l & 15, q = l >> 4) of tile (ct, j) holds
+//   A: weights  [cout = ct*16 + n][k = 8q .. 8q+7]      (chunk q of the k32 block)
+//   B: act      [k = 8q .. 8q+7][row = row0(j) + n]     (chunk 4*q32 + q of that row's slot)
+//   D: acc[ct][j][i] = out[cout = ct*16 + 4q + i][row = row0(j) + n]
+// i.e. again 4 consecutive output channels of ONE board point per accumulator quad, so
+// epilogues keep writing 8-byte fp16 pieces.
+#pragma once
+#include <type_traits>
+#include "conv_core.h"
+
+namespace p3 {
+
+template <class G, int COUT_PASS>
+struct Tiling16 {
+  using T = Tiling<G, COUT_PASS>;
+  static constexpr int CG = T::CG, LG = T::LG;
+  static constexpr int MT = 4;           // cout tiles of 16 per wave
+  static constexpr int NT = 2 * T::NT;   // location tiles of 16 per wave
+  static constexpr int RS = T::RS;
+  static_assert(NT >= MT, "A reads are spread over the first MT location groups");
+};
+
+// Padded-grid row of lane column n of location tile j (16 rows) of wave group lg;
+// *valid_tile is false for the padding tiles of an uneven split (recomputed, never stored).
+template <class G, int COUT_PASS>
+__device__ __forceinline__ int tile16_slot0(int lg, int j, bool* valid_tile = nullptr) {
+  using T = Tiling16<G, COUT_PASS>;
+  int t = lg + (j >> 1) * T::LG;
+  const bool ok = t < G::NT_TOTAL;
+  if (!ok) t = lg;
+  if (valid_tile) *valid_tile = ok;
+  const int p = t / G::NT_POS, tt = t - p * G::NT_POS;
+  return p * G::PSLOTS + G::PADTOP + tt * 32 + (j & 1) * 16;
+}
+
+template <int NTn>
+__device__ __forceinline__ void acc16_zero(f32x4 (&acc)[4][NTn]) {
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int j = 0; j < NTn; ++j) acc[ct][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// One conv segment, acc[ct][j] += W_seg x act over NK k32-steps (tap major).  Fragments
+// are fetched ONE step ahead: the four A fragments are double-buffered, the B fragment of
+// location tile j is reloaded in place right after its four MFMAs have issued, so the read
+// has a full step (>= 20 MFMAs) to land.  Issue order per step: after location group 0:
+// B_0', A_0', A_1'; after group 1: B_1', A_2', A_3'; after group j >= 2: B_j'.  The counted
+// lgkmcnt waits below follow from that order.
+//
+// Addressing: one VGPR per 32-row tile pair (at kernel row ky, leftmost tap);
+// kernel column kx, the odd 16-row tile and the k32 index inside the tap are immediates.
+// Body = one kernel row (KW taps), runtime loop over ky.
+template <class G, int COUT_PASS, int KW, int NTAPS_PAD, bool STAMPS = false, int NTn = 0>
+__device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS)>& ring, char* smem,
+                                               f32x4 (&acc)[4][NTn]) {
+  using T = Tiling16<G, COUT_PASS>;
+  static_assert(NTn == T::NT, "accumulator shape");
+  static_assert(G::CB % 32 == 0 && NTAPS_PAD == KW * KW, "k32 steps, unpadded taps");
+  constexpr int NT = T::NT, NB = NT / 2;
+  constexpr int NQ = G::CB / 32;                   // k32-steps per tap
+  constexpr int U = KW * NQ;                       // unrolled body: one kernel row
+  constexpr int NOUT = KW;
+  static_assert(U % 2 == 0, "segment shape");
+  constexpr int KB = COUT_PASS * 32;               // bytes per k16 block of the weight panel
+  const int lane = launder(threadIdx.x & 63);
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = wid % T::CG, lg = wid / T::CG;
+  const int n = lane & 15, q = lane >> 4;
+
+  const uint32_t a_off = (uint32_t)((q >> 1) * KB + ((q & 1) * COUT_PASS + cg * 64 + n) * 16);
+  uint32_t a_addr = 0;
+  uint32_t b_row[NB];                              // byte address for the kernel row being fetched
+  h8 fa[2][4], fb[NT];
+
+  // LDS reads of static step V (may be U = first step of the next body) issued after
+  // location group J of the step before it; o = body of step 0.
+  auto fetch_piece = [&](int o, auto V, auto J) {
+    constexpr int v = decltype(V)::value, j = decltype(J)::value;
+    constexpr int vv = v % U;
+    constexpr int kk = vv % 2;                     // k32 index inside the ring macro-step
+    constexpr int q32 = vv % NQ;                   // k32 index inside the tap
+    constexpr int kx = vv / NQ;
+    constexpr int nxt = v % 2;                     // U is even: parity of the global step
+    if constexpr (j == 0) {
+      // mid-segment acquires leave this wave's B_2'..B_(NT-1)' reloads of the previous
+      // step in flight: every A read of the macro-step being recycled is older than them
+      if constexpr (kk == 0) {
+        if constexpr (v == 0) a_addr = ring_acquire<STAMPS, 0>(ring, smem) + a_off;
+        else a_addr = ring_acquire<STAMPS, NT - 2>(ring, smem) + a_off;
+      }
+      if constexpr (vv == 0) {
+        const int ky = o + v / U;
+        const int rowshift = (ky - KW / 2) * G::S - KW / 2;   // tap (ky, kx = 0)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          b_row[b] = (uint32_t)((tile16_slot0<G, COUT_PASS>(lg, 2 * b) + n + rowshift) * G::SLOTB + q * 16);
+      }
+    }
+    constexpr int BOFF = kx * G::SLOTB + (j & 1) * 16 * G::SLOTB + q32 * 64;
+    fb[j] = lds_read128<BOFF>(b_row[j >> 1]);
+    if constexpr (j < 2) {
+      constexpr int AOFF = kk * 2 * KB + j * 512;
+      fa[nxt][2 * j] = lds_read128<AOFF>(a_addr);
+      fa[nxt][2 * j + 1] = lds_read128<AOFF + 256>(a_addr);
+    }
+  };
+
+  static_for<0, NT>([&](auto J) { fetch_piece(0, std::integral_constant<int, 0>{}, J); });
+#pragma unroll 1
+  for (int o = 0; o < NOUT; ++o) {
+    const bool last_body = (NOUT == 1) || (o + 1 == NOUT);
+    static_for<0, U>([&](auto UU) {
+      constexpr int u = decltype(UU)::value;
+      bool do_fetch = (u + 1 < U) || !last_body;
+      if (STAMPS && (ring.dbg & 2)) do_fetch = false;  // timing experiment: MFMAs only
+      static_for<0, NT>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        // group 0 needs B_0 and the four A fragments (A_3' is the youngest): only
+        // B_2'.. of the previous step's fetch may still be outstanding; that covers group 1.
+        // Group j >= 2 needs B_j': younger are B_(j+1)'.. plus this step's reads so far
+        // (groups 0, 1: three each, groups 2..j-1: one each) = NT + 3, or NT - 1 - j
+        // when this step fetches nothing.
+        if constexpr (j == 0) wait_lgkm<NT - 2>();
+        else if constexpr (j >= 2) {
+          if (do_fetch) wait_lgkm<NT + 3>();
+          else wait_lgkm<NT - 1 - j>();
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[u % 2][ct], fb[j], acc[ct][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_fetch) fetch_piece(o, std::integral_constant<int, u + 1>{}, J);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  }
+}
+
+// ---- epilogues ---------------------------------------------------------------------------
+struct EpiParams16 { f32x4 sc[4], sh[4]; };
+
+template <class G, int COUT_PASS>
+__device__ __forceinline__ void epi_params16(EpiParams16& ep, const float* __restrict__ scale,
+                                             const float* __restrict__ shift, int cofs) {
+  const int q = launder(threadIdx.x & 63) >> 4;
+  const int c0 = cofs + cg_of<G, COUT_PASS>() * 64 + q * 4;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    ep.sc[ct] = *(const f32x4*)(scale + c0 + 16 * ct);
+    ep.sh[ct] = *(const f32x4*)(shift + c0 + 16 * ct);
+  }
+}
+
+template <int NTn>
+struct EpiOut16 { h4 o[NTn][4]; };
+
+// BN + mish + fp16 pack in registers (may run before the barrier that frees the act buffer).
+template <int NTn>
+__device__ __forceinline__ void epilogue_math16(EpiOut16<NTn>& eo, f32x4 (&acc)[4][NTn],
+                                                const EpiParams16& ep) {
+#pragma unroll
+  for (int j = 0; j < NTn; ++j) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        eo.o[j][ct][i] = (_Float16)mish_f(acc[ct][j][i] * ep.sc[ct][i] + ep.sh[ct][i]);
+    __builtin_amdgcn_sched_barrier(0);   // one tile at a time: bounds the live temporaries
+  }
+}
+
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void epilogue_write16(char* smem, const EpiOut16<NTn>& eo, int cofs) {
+  using T = Tiling16<G, COUT_PASS>;
+  const int lane = launder(threadIdx.x & 63);
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lg = wid / T::CG;
+  const int n = lane & 15, q = lane >> 4;
+  const uint32_t coff = (uint32_t)(((cofs >> 3) + cg_of<G, COUT_PASS>() * 8 + (q >> 1)) * 16 + (q & 1) * 8);
+#pragma unroll
+  for (int j = 0; j < NTn; ++j) {
+    const int t = lg + (j >> 1) * T::LG;
+    const int tv = t < G::NT_TOTAL ? t : lg;
+    const int p = tv / G::NT_POS, tt = tv - p * G::NT_POS;
+    const int r = tt * 32 + (j & 1) * 16 + n;       // row inside its position
+    int loc;
+    const bool ok = row_valid<G::S>(r, loc) && (t < G::NT_TOTAL);
+    const uint32_t dst = (uint32_t)((p * G::PSLOTS + G::PADTOP + r) * G::SLOTB) + coff;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      if (ok) *(h4*)(smem + dst + ct * 32) = eo.o[j][ct];
+  }
+}
+
+// Full layer transition: parameters, math, barrier, stores.
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void epilogue_layer16(char* smem, f32x4 (&acc)[4][NTn],
+                                                 const float* __restrict__ scale,
+                                                 const float* __restrict__ shift) {
+  EpiOut16<NTn> eo;
+  {
+    EpiParams16 ep;
+    epi_params16<G, COUT_PASS>(ep, scale, shift, 0);
+    epilogue_math16<NTn>(eo, acc, ep);
+  }
+  lds_barrier();
+  epilogue_write16<G, COUT_PASS, NTn>(smem, eo, 0);
+}
+
+// ---- expand epilogue: out = acc + residual -> fp16 global [pos][C/8][361][8] ---------------
+template <int NTn>
+struct ResRegs16 {
+  h4 rv[NTn][4];
+  uint32_t base[NTn];   // element offset of (ct = 0) inside x
+  bool ok[NTn];
+};
+
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void residual_addr16(ResRegs16<NTn>& rr, int C, int pos0, int npos, int cofs) {
+  using T = Tiling16<G, COUT_PASS>;
+  const int lane = launder(threadIdx.x & 63);
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lg = wid / T::CG;
+  const int n = lane & 15, q = lane >> 4;
+  const int cblk = ((cofs + cg_of<G, COUT_PASS>() * 64) >> 3) + (q >> 1);   // channel block of ct = 0
+#pragma unroll
+  for (int j = 0; j < NTn; ++j) {
+    const int t = lg + (j >> 1) * T::LG;
+    const int tv = t < G::NT_TOTAL ? t : lg;
+    const int p = tv / G::NT_POS, tt = tv - p * G::NT_POS;
+    int loc;
+    rr.ok[j] = row_valid<G::S>(tt * 32 + (j & 1) * 16 + n, loc) && (pos0 + p < npos) && (t < G::NT_TOTAL);
+    if (!rr.ok[j]) loc = 0;
+    const int pp = (pos0 + p < npos) ? pos0 + p : npos - 1;
+    rr.base[j] = (uint32_t)((pp * (C / 8) + cblk) * (kNLoc * 8) + loc * 8 + (q & 1) * 4);
+  }
+}
+
+// Issues exactly NTn*4 = 24 loads per lane (invalid rows read a valid dummy address).
+// Addresses are (uniform base of the cout tile's channel block) + (32-bit lane offset), the
+// SGPR-base form of global_load: six offset registers instead of 24 64-bit pointers.
+template <int NTn>
+__device__ __forceinline__ void residual_load16(ResRegs16<NTn>& rr, const _Float16* __restrict__ x) {
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const char* xc = (const char*)x + (size_t)ct * (2 * kNLoc * 8 * 2);   // channel block +2 per cout tile
+#pragma unroll
+    for (int j = 0; j < NTn; ++j) rr.rv[j][ct] = *(const h4*)(xc + (uint32_t)(rr.base[j] * 2u));
+  }
+}
+
+template <bool RESIDUAL, int NTn>
+__device__ __forceinline__ void epilogue_store16(f32x4 (&acc)[4][NTn], const ResRegs16<NTn>& rr,
+                                                 _Float16* __restrict__ x) {
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    char* xc = (char*)x + (size_t)ct * (2 * kNLoc * 8 * 2);
+#pragma unroll
+    for (int j = 0; j < NTn; ++j) {
+      h4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[ct][j][i];
+        if (RESIDUAL) v += (float)rr.rv[j][ct][i];
+        o[i] = (_Float16)v;
+      }
+      if (rr.ok[j]) *(h4*)(xc + (uint32_t)(rr.base[j] * 2u)) = o;
+    }
+  }
+}
+
+}  // namespace p3

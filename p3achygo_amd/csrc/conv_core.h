@@ -160,7 +160,11 @@ __device__ __forceinline__ void ring_init(Ring<RS>& r, char* smem, const void* g
 // right after the D*G glds (ring_note_xloads): for the next D acquires the pieces that must
 // have landed are still older than all of them, so the count to leave outstanding is
 // (D-1)*G + kXLoads; the (D+1)-th acquire waits with vmcnt((D-1)*G) again, which retires them.
-template <bool STAMPS = false, int RS = 0>
+// LGKM = LDS operations of this wave that may stay outstanding across the acquire: 0 for
+// the first acquire of a segment (it doubles as the "previous layer written" barrier); a
+// K loop that knows how many reads it issued after the last fragment read of the macro-step
+// being recycled passes that count instead and does not stall on its own recent reads.
+template <bool STAMPS = false, int LGKM = 0, int RS = 0>
 __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
   static_assert(kRingDepth == 2 && kXLoads == 12, "vmcnt immediates below");
   unsigned long long t0 = 0;
@@ -176,18 +180,18 @@ __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
   if (r.tol > 0) {
     r.tol--;
     if (r.extra == 12) {
-      if (G == 2) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory");
+      if (G == 2) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
+      else asm volatile("s_waitcnt vmcnt(13) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
     } else if (r.extra == 24) {
-      if (G == 2) asm volatile("s_waitcnt vmcnt(26) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(25) lgkmcnt(0)" ::: "memory");
+      if (G == 2) asm volatile("s_waitcnt vmcnt(26) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
+      else asm volatile("s_waitcnt vmcnt(25) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
     } else {
-      if (G == 2) asm volatile("s_waitcnt vmcnt(50) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(49) lgkmcnt(0)" ::: "memory");
+      if (G == 2) asm volatile("s_waitcnt vmcnt(50) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
+      else asm volatile("s_waitcnt vmcnt(49) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
     }
   } else {
-    if (G == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    if (G == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
+    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -253,6 +257,20 @@ template <int N>
 __device__ __forceinline__ void wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
   __builtin_amdgcn_sched_barrier(0);
+}
+
+// wait_lgkm for a count that is static only after unrolling
+__device__ __forceinline__ void wait_lgkm_n(int n) {
+  switch (n) {
+    case 0: wait_lgkm<0>(); break;
+    case 1: wait_lgkm<1>(); break;
+    case 2: wait_lgkm<2>(); break;
+    case 3: wait_lgkm<3>(); break;
+    case 4: wait_lgkm<4>(); break;
+    case 5: wait_lgkm<5>(); break;
+    case 6: wait_lgkm<6>(); break;
+    default: wait_lgkm<7>(); break;
+  }
 }
 
 // One conv segment: acc[mt][j] += W_seg x act over NK16 k16-steps taken in the order
@@ -423,9 +441,28 @@ __device__ __forceinline__ void epi_params(EpiParams& ep, const float* __restric
   }
 }
 
+// The epilogue is split at the barrier: epilogue_math (BN + mish + fp16 pack, registers
+// only) runs BEFORE the barrier that retires the readers of the act buffer, so the wave of
+// a SIMD pair that finishes its K loop first transforms its tile under the other wave's
+// MFMAs; epilogue_write (LDS stores only) runs after it.
+template <int NTn>
+struct EpiOut { h4 o[NTn][8]; };
+
 template <class G, int COUT_PASS, int NTn>
-__device__ __forceinline__ void epilogue_to_act(char* smem, f32x16 (&acc)[2][NTn],
-                                                const EpiParams& ep, int cofs) {
+__device__ __forceinline__ void epilogue_math(EpiOut<NTn>& eo, f32x16 (&acc)[2][NTn], const EpiParams& ep) {
+#pragma unroll
+  for (int j = 0; j < NTn; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int mt = k >> 2, g4 = k & 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        eo.o[j][k][i] = (_Float16)mish_f(acc[mt][j][g4 * 4 + i] * ep.sc[k][i] + ep.sh[k][i]);
+    }
+}
+
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void epilogue_write(char* smem, const EpiOut<NTn>& eo, int cofs) {
   using T = Tiling<G, COUT_PASS>;
   const int lane = launder(threadIdx.x & 63);
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -442,15 +479,32 @@ __device__ __forceinline__ void epilogue_to_act(char* smem, f32x16 (&acc)[2][NTn
     const bool ok = row_valid<G::S>(r, loc);
     const uint32_t dst = (uint32_t)((p * G::PSLOTS + G::PADTOP + r) * G::SLOTB + cblk0 * 16 + h * 8);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int mt = k >> 2, g4 = k & 3;
-      h4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        o[i] = (_Float16)mish_f(acc[mt][j][g4 * 4 + i] * ep.sc[k][i] + ep.sh[k][i]);
-      if (ok) *(h4*)(smem + dst + k * 16) = o;
-    }
+    for (int k = 0; k < 8; ++k)
+      if (ok) *(h4*)(smem + dst + k * 16) = eo.o[j][k];
   }
+}
+
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void epilogue_to_act(char* smem, f32x16 (&acc)[2][NTn],
+                                                const EpiParams& ep, int cofs) {
+  EpiOut<NTn> eo;
+  epilogue_math<G, COUT_PASS, NTn>(eo, acc, ep);
+  epilogue_write<G, COUT_PASS, NTn>(smem, eo, cofs);
+}
+
+// Full layer transition: parameters, math, barrier, stores.
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void epilogue_layer(char* smem, f32x16 (&acc)[2][NTn],
+                                               const float* __restrict__ scale,
+                                               const float* __restrict__ shift) {
+  EpiOut<NTn> eo;
+  {
+    EpiParams ep;
+    epi_params<G, COUT_PASS>(ep, scale, shift, 0);
+    epilogue_math<G, COUT_PASS, NTn>(eo, acc, ep);
+  }
+  lds_barrier();
+  epilogue_write<G, COUT_PASS, NTn>(smem, eo, 0);
 }
 
 // Staging of a CB-channel slice (channel blocks cblk0 .. cblk0+NCH-1) of the residual
@@ -514,6 +568,29 @@ __device__ __forceinline__ void stage_store(char* smem, const XRegs<G>& xr, int 
     const int sl = p * G::PSLOTS + G::PADTOP + y * G::S + xx;
     *(h8*)(smem + sl * G::SLOTB + kc * 16) = o;
     if (i & 1) __builtin_amdgcn_sched_barrier(0);  // bound the live range: 2 items in flight
+  }
+}
+
+// BN + mish of a fetched slice in place (registers only), so that it can run before the
+// barrier that frees the act buffer; pair with stage_store<G, false>.
+template <class G>
+__device__ __forceinline__ void stage_math(XRegs<G>& xr, int cblk0, const float* __restrict__ scale,
+                                           const float* __restrict__ shift) {
+  const int combo = launder(threadIdx.x) >> 5;
+  const int kc = combo % G::NCH;
+  const int c = (cblk0 + kc) * 8;
+  const f32x4 s0 = *(const f32x4*)(scale + c), s1 = *(const f32x4*)(scale + c + 4);
+  const f32x4 t0 = *(const f32x4*)(shift + c), t1 = *(const f32x4*)(shift + c + 4);
+#pragma unroll
+  for (int i = 0; i < kXLoads; ++i) {
+    const h8 v = xr.v[i];
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = (_Float16)mish_f((float)v[e] * s0[e] + t0[e]);
+      o[e + 4] = (_Float16)mish_f((float)v[e + 4] * s1[e] + t1[e]);
+    }
+    xr.v[i] = o;
   }
 }
 

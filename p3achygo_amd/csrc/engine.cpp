@@ -609,7 +609,9 @@ double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
   hipStreamSynchronize(e->stream);
   const float ms = (float)total_ms;
   const double n3 = (wf.btype == 0) ? wf.inner : 4;
-  if (flops_per_launch) *flops_per_launch = 2.0 * n_positions * kNLoc * n3 * 9.0 * wf.Cb * wf.Cb;
+  // every conv the block kernel executes: the inner 3x3s plus the 1x1 reduce and expand
+  if (flops_per_launch)
+    *flops_per_launch = 2.0 * n_positions * kNLoc * (n3 * 9.0 * wf.Cb * wf.Cb + 2.0 * wf.C * wf.Cb);
   if (kernel_name) *kernel_name = p3::block_kernel_name(C, bp->kind, wf.inner);
   return ms / iters;
 }

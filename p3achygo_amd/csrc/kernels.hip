@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "conv_core.h"
+#include "conv16.h"
 
 namespace p3 {
 
@@ -38,7 +39,8 @@ template <int C, int CB, int KIND, int L, bool STAMPS = false>
 __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
   constexpr int NPOS = 128 / CB;
   using G = Geo<NPOS, CB, 3>;
-  using T = Tiling<G, CB>;
+  using T = Tiling16<G, CB>;
+  constexpr int NT = T::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr uint32_t kRingOff = G::ACT_BYTES;
 
@@ -51,110 +53,84 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
   static_assert(C / CB == 2, "two input slices / two output passes");
   XRegs<G> xr;
   stage_load<G>(xr, a.x, C, blockIdx.x * NPOS, a.npos, 0);
+  stage_math<G>(xr, 0, a.scale[0], a.shift[0]);
   int npos_done = 0;
   for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS, ++npos_done) {
-    f32x16 acc[2][T::NT];
+    f32x4 acc[4][NT];
     P3_STAMP(0);
-    // ---- reduce 1x1 (C -> CB), prologue bn0+mish applied while staging; slice 1 is
-    // fetched into registers under the slice-0 MFMAs ------------------------------------
-    stage_store<G, true>(smem, xr, 0, a.scale[0], a.shift[0]);
-    acc_zero<G, CB>(acc);
+    // ---- reduce 1x1 (C -> CB), prologue bn0+mish applied to the fetched slice in
+    // registers; slice 1 is fetched under the slice-0 MFMAs -------------------------------
+    stage_store<G, false>(smem, xr, 0, nullptr, nullptr);
+    acc16_zero<NT>(acc);
     stage_load<G>(xr, a.x, C, pos0, a.npos, G::NCH);
     ring_note_xloads(ring);
     P3_STAMP(1);
-    conv_segment<G, CB, 1, 1, STAMPS>(ring, smem, acc);
+    conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
     P3_STAMP(2);
+    stage_math<G>(xr, G::NCH, a.scale[0], a.shift[0]);
     lds_barrier();
-    stage_store<G, true>(smem, xr, G::NCH, a.scale[0], a.shift[0]);
+    stage_store<G, false>(smem, xr, G::NCH, nullptr, nullptr);
     P3_STAMP(3);
-    conv_segment<G, CB, 1, 1, STAMPS>(ring, smem, acc);
+    conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
     P3_STAMP(4);
-    // The next position's first slice is fetched into registers under the last 3x3 conv.
     const int pos_next = pos0 + gridDim.x * NPOS;
     if (KIND == 0) {
-#pragma unroll 1
+#pragma unroll
       for (int j = 1; j <= L; ++j) {
-        {
-          EpiParams ep;
-          epi_params<G, CB>(ep, a.scale[j], a.shift[j], 0);
-          lds_barrier();
-          epilogue_to_act<G, CB>(smem, acc, ep, 0);
-        }
-        acc_zero<G, CB>(acc);
+        epilogue_layer16<G, CB, NT>(smem, acc, a.scale[j], a.shift[j]);
+        acc16_zero<NT>(acc);
         P3_STAMP(3 + 2 * j);
-        if (j == L) {
-          stage_load<G>(xr, a.x, C, pos_next, a.npos, 0);
-          ring_note_xloads(ring);
-        }
-        conv_segment<G, CB, 3, 9, STAMPS>(ring, smem, acc);
+        conv_segment16<G, CB, 3, 9, STAMPS>(ring, smem, acc);
         P3_STAMP(4 + 2 * j);
         if (STAMPS && (threadIdx.x & 63) == 0 && npos_done < 4) {
           const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
           a.stamps[((blockIdx.x * 8 + w_) * 4 + npos_done) * 32 + 20 + j] = ring.wait_cycles;
         }
       }
-      {
-        EpiParams ep;
-        epi_params<G, CB>(ep, a.scale[L + 1], a.shift[L + 1], 0);
-        lds_barrier();
-        epilogue_to_act<G, CB>(smem, acc, ep, 0);
-      }
+      epilogue_layer16<G, CB, NT>(smem, acc, a.scale[L + 1], a.shift[L + 1]);
       P3_STAMP(11);
     } else {
       // nbt: keep the raw inner residual t in registers (fp32, same tile as acc)
-      f32x16 t[2][T::NT];
+      f32x4 t[4][NT];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int j = 0; j < T::NT; ++j) t[mt][j] = acc[mt][j];
+        for (int j = 0; j < NT; ++j) t[ct][j] = acc[ct][j];
 #pragma unroll 1
       for (int r = 0; r < 2; ++r) {
-        {
-          EpiParams ep;
-          epi_params<G, CB>(ep, a.scale[1 + 2 * r], a.shift[1 + 2 * r], 0);
-          lds_barrier();
-          epilogue_to_act<G, CB>(smem, t, ep, 0);
-        }
-        acc_zero<G, CB>(acc);
-        conv_segment<G, CB, 3, 9, STAMPS>(ring, smem, acc);
-        {
-          EpiParams ep;
-          epi_params<G, CB>(ep, a.scale[2 + 2 * r], a.shift[2 + 2 * r], 0);
-          lds_barrier();
-          epilogue_to_act<G, CB>(smem, acc, ep, 0);
-        }
-        acc_zero<G, CB>(acc);
-        conv_segment<G, CB, 3, 9, STAMPS>(ring, smem, acc);
+        epilogue_layer16<G, CB, NT>(smem, t, a.scale[1 + 2 * r], a.shift[1 + 2 * r]);
+        acc16_zero<NT>(acc);
+        conv_segment16<G, CB, 3, 9, STAMPS>(ring, smem, acc);
+        epilogue_layer16<G, CB, NT>(smem, acc, a.scale[2 + 2 * r], a.shift[2 + 2 * r]);
+        acc16_zero<NT>(acc);
+        conv_segment16<G, CB, 3, 9, STAMPS>(ring, smem, acc);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-          for (int j = 0; j < T::NT; ++j) t[mt][j] += acc[mt][j];
+          for (int j = 0; j < NT; ++j) t[ct][j] += acc[ct][j];
       }
-      {
-        EpiParams ep;
-        epi_params<G, CB>(ep, a.scale[5], a.shift[5], 0);
-        lds_barrier();
-        epilogue_to_act<G, CB>(smem, t, ep, 0);
-      }
-      stage_load<G>(xr, a.x, C, pos_next, a.npos, 0);
-      ring_note_xloads(ring);
+      epilogue_layer16<G, CB, NT>(smem, t, a.scale[5], a.shift[5]);
     }
     // ---- expand 1x1 (CB -> C) + residual, straight to HBM.  The residual of each output
     // pass is loaded before that pass's MFMAs (24 loads/lane); in pass 1 the 24 stores of
     // pass 0 are in flight as well ------------------------------------------------------
     P3_STAMP(12);
-#pragma unroll 1
-    for (int cp = 0; cp < C / CB; ++cp) {
-      ResRegs<G, CB, T::NT> rr;
-      residual_addr<G, CB, T::NT>(rr, C, pos0, a.npos, cp * CB);
-      residual_load<G, CB, T::NT>(rr, a.x);
-      if (KIND == 0) ring_note_inflight(ring, cp == 0 ? 24 : 48);
-      acc_zero<G, CB>(acc);
-      conv_segment<G, CB, 1, 1, STAMPS>(ring, smem, acc);
+#pragma unroll
+    for (int cp = 0; cp < C / CB; ++cp) {   // fully unrolled: xr must not look live across passes
+      ResRegs16<NT> rr;
+      residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, cp * CB);
+      residual_load16<NT>(rr, a.x);
+      ring_note_inflight(ring, cp == 0 ? 24 : 48);
+      acc16_zero<NT>(acc);
+      conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
       P3_STAMP(13 + 2 * cp);
-      epilogue_store<G, CB, true, T::NT>(acc, rr, a.x);
+      // next position's first slice: issued once the last K loop of this position is over
+      // (no fragment registers live), lands under the residual epilogue's stores
+      if (cp == C / CB - 1) stage_load<G>(xr, a.x, C, pos_next, a.npos, 0);
+      epilogue_store16<true, NT>(acc, rr, a.x);
       P3_STAMP(14 + 2 * cp);
     }
+    stage_math<G>(xr, 0, a.scale[0], a.shift[0]);   // next position's slice 0, before the barrier
     lds_barrier();
     P3_STAMP(17);
   }

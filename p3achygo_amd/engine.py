@@ -20,7 +20,8 @@ import numpy as np
 from .features import RAW_LEN, Features, Result
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libp3hip.so")
+# P3HIP_LIB lets tools/gpu_ab.py time two builds of the kernels side by side.
+LIB_PATH = os.environ.get("P3HIP_LIB") or os.path.join(_HERE, "csrc", "libp3hip.so")
 
 EXPORTS = [
     "p3hip_create", "p3hip_create_error", "p3hip_destroy", "p3hip_kind", "p3hip_path",
@@ -31,7 +32,6 @@ EXPORTS = [
 
 FLAG_NO_GRAPH = 1
 FLAG_RUN_ALL_SLOTS = 2
-FLAG_LAYERWISE = 4
 
 
 class EngineError(RuntimeError):

@@ -412,142 +412,271 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// block-wide (256 threads) reductions through LDS scratch `red` (>= 8 floats)
-__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
-  v = is_max ? wave_max(v) : wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float r = red[0];
-  for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
-  return r;
-}
+// LDS plan of k_heads (float offsets): every small weight matrix of the heads staged once
+// per workgroup, then one scratch area per 256-thread position group.
+template <int H, int V>
+struct HeadsLds {
+  static constexpr int gd_w = 0;                               // [2H][H]
+  static constexpr int oq_embed_w = gd_w + 2 * H * H;          // [2H][V]
+  static constexpr int gamma_pre_w = oq_embed_w + 2 * H * V;   // [2H][V]
+  static constexpr int score_pre_w = gamma_pre_w + 2 * H * V;  // [2H+1][V]
+  static constexpr int oq_out_w = score_pre_w + (2 * H + 1) * V;  // [V][14]
+  static constexpr int gamma_out_w = oq_out_w + V * 14;        // [V]
+  static constexpr int score_out_w = gamma_out_w + V;          // [V]
+  static constexpr int pass_w = score_out_w + V;               // [2H][2]
+  static constexpr int opt_pass_w = pass_w + 4 * H;            // [2H]
+  static constexpr int moves_w = opt_pass_w + 2 * H;           // [H][2]
+  static constexpr int opt_moves_w = moves_w + 2 * H;          // [H]
+  static constexpr int own_w = opt_moves_w + H;                // [H]
+  static constexpr int gbn_scale = own_w + H;                  // [H]
+  static constexpr int gbn_shift = gbn_scale + H;              // [H]
+  static constexpr int gd_b = gbn_shift + H;                   // [H]
+  static constexpr int oq_embed_b = gd_b + H;                  // [V]
+  static constexpr int gamma_pre_b = oq_embed_b + V;           // [V]
+  static constexpr int score_pre_b = gamma_pre_b + V;          // [V]
+  static constexpr int oq_out_b = score_pre_b + V;             // [14] (+2 pad)
+  static constexpr int n_weights = oq_out_b + 16;
+  // per position group
+  static constexpr int gp = 0, vp = gp + 2 * H, gbias = vp + 2 * H, emb = gbias + H, gpre = emb + V,
+                       base = gpre + V, red = base + V, misc = red + 16, logits = misc + 4,
+                       pi = logits + 800, opt = pi + 364, n_scratch = opt + 364;
+  static constexpr int kGroups = 4;
+  static constexpr size_t bytes = (size_t)(n_weights + kGroups * n_scratch) * 4;
+};
 
-__device__ void softmax_block(const float* in, float* out, int n, float* red) {
-  float m = -3.0e38f;
-  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, in[i]);
-  m = block_reduce(m, red, true);
-  float s = 0.0f;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    float e = __expf(in[i] - m);
-    out[i] = e;
-    s += e;
-  }
-  s = block_reduce(s, red, false);
-  const float inv = 1.0f / s;
-  for (int i = threadIdx.x; i < n; i += 256) out[i] *= inv;
-}
-
-template <int H>
-__global__ void __launch_bounds__(256) k_heads(HeadsArgs a) {
+// One 1024-thread workgroup evaluates the heads of four positions at a time, one per
+// 256-thread group; all groups run the same phases in lockstep (block-wide barriers).
+// Every weight is read from LDS; the only global traffic inside the phases is the head
+// conv output `hp` (each value once or twice, coalesced) and the result row.
+template <int H, int V>
+__global__ void __launch_bounds__(1024) k_heads(HeadsArgs a) {
   static_assert(H == 32, "head channels");
-  __shared__ float gp[2 * H], vp[2 * H], gbias[H], emb[128], gpre[128], base[128], red[8];
-  __shared__ float s_logits[800], s_pi[362], s_opt[362];
-  __shared__ float s_misc[4];
-  const int V = a.V;
-  for (int pos = blockIdx.x; pos < a.npos; pos += gridDim.x) {
-    const float* hp = a.hp + (size_t)pos * 3 * H * kNLoc;
-    float* out = a.out + (size_t)pos * kOutStride;
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // ---- pooled g (after bn+mish) and pooled v (raw): one wave per channel ----------
-    for (int c = wid; c < 2 * H; c += 4) {
-      const bool is_g = c < H;
-      const int ch = is_g ? c : c - H;
-      const float* src = hp + (size_t)(is_g ? H + ch : 2 * H + ch) * kNLoc;
-      const float sc = is_g ? a.gbn_scale[ch] : 1.0f, sh = is_g ? a.gbn_shift[ch] : 0.0f;
-      float s = 0.0f, m = -3.0e38f;
-      for (int i = lane; i < kNLoc; i += 64) {
-        float v = src[i];
-        if (is_g) v = mish_f(v * sc + sh);
-        s += v;
-        m = fmaxf(m, v);
+  using L = HeadsLds<H, V>;
+  extern __shared__ __attribute__((aligned(16))) float hl[];
+  const int tid = threadIdx.x, g = tid >> 8, t = tid & 255;
+  const int wid = t >> 6, lane = t & 63;
+  auto stage = [&](int off, const float* __restrict__ src, int n) {
+    for (int i = tid; i < n; i += 1024) hl[off + i] = src[i];
+  };
+  stage(L::gd_w, a.gd_w, 2 * H * H);
+  stage(L::oq_embed_w, a.oq_embed_w, 2 * H * V);
+  stage(L::gamma_pre_w, a.gamma_pre_w, 2 * H * V);
+  stage(L::score_pre_w, a.score_pre_w, (2 * H + 1) * V);
+  stage(L::oq_out_w, a.oq_out_w, V * 14);
+  stage(L::gamma_out_w, a.gamma_out_w, V);
+  stage(L::score_out_w, a.score_out_w, V);
+  stage(L::pass_w, a.pass_w, 4 * H);
+  stage(L::opt_pass_w, a.opt_pass_w, 2 * H);
+  stage(L::moves_w, a.moves_w, 2 * H);
+  stage(L::opt_moves_w, a.opt_moves_w, H);
+  stage(L::own_w, a.own_w, H);
+  stage(L::gbn_scale, a.gbn_scale, H);
+  stage(L::gbn_shift, a.gbn_shift, H);
+  stage(L::gd_b, a.gd_b, H);
+  stage(L::oq_embed_b, a.oq_embed_b, V);
+  stage(L::gamma_pre_b, a.gamma_pre_b, V);
+  stage(L::score_pre_b, a.score_pre_b, V);
+  stage(L::oq_out_b, a.oq_out_b, 14);
+  const float pass_b0 = a.pass_b[0], opt_pass_b = a.opt_pass_b[0], gamma_out_b = a.gamma_out_b[0],
+              score_out_b = a.score_out_b[0];
+  float* sc = hl + L::n_weights + g * L::n_scratch;
+  __syncthreads();
+
+  for (int pos4 = blockIdx.x * L::kGroups; pos4 < a.npos; pos4 += gridDim.x * L::kGroups) {
+    const bool live = pos4 + g < a.npos;
+    const int pos = live ? pos4 + g : a.npos - 1;   // idle groups recompute the last position
+    const float* __restrict__ hp = a.hp + (size_t)pos * 3 * H * kNLoc;
+    float* __restrict__ out = a.out + (size_t)pos * kOutStride;
+    // ---- pooled g (after bn+mish) and pooled v (raw): one wave per channel, two channels
+    // (12 loads) in flight -----------------------------------------------------------------
+    for (int c0 = wid; c0 < 2 * H; c0 += 8) {
+      float v[2][6];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = c0 + 4 * u;                 // g channels are c < H, v channels c >= H
+        const float* src = hp + (size_t)(H + c) * kNLoc;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const int i = lane + 64 * k;
+          v[u][k] = src[i < kNLoc ? i : kNLoc - 1];
+        }
       }
-      s = wave_sum(s);
-      m = wave_max(m);
-      if (lane == 0) {
-        float* dst = is_g ? gp : vp;
-        dst[ch] = s * (1.0f / kNLoc);
-        dst[H + ch] = m;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = c0 + 4 * u;
+        const bool is_g = c < H;
+        const int ch = is_g ? c : c - H;
+        const float bsc = is_g ? hl[L::gbn_scale + ch] : 1.0f, bsh = is_g ? hl[L::gbn_shift + ch] : 0.0f;
+        float s = 0.0f, m = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          float x = v[u][k];
+          if (is_g) x = mish_f(x * bsc + bsh);
+          if (lane + 64 * k < kNLoc) {
+            s += x;
+            m = fmaxf(m, x);
+          }
+        }
+        s = wave_sum(s);
+        m = wave_max(m);
+        if (lane == 0) {
+          float* dst = sc + (is_g ? L::gp : L::vp);
+          dst[ch] = s * (1.0f / kNLoc);
+          dst[H + ch] = m;
+        }
       }
     }
     __syncthreads();
     // ---- small dense layers ----------------------------------------------------------
-    if (threadIdx.x < H) {
-      float s = a.gd_b[threadIdx.x];
-      for (int k = 0; k < 2 * H; ++k) s += gp[k] * a.gd_w[k * H + threadIdx.x];
-      gbias[threadIdx.x] = s;
-    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + V) {
-      const int o = threadIdx.x - 64;
-      float s = a.oq_embed_b[o], g = a.gamma_pre_b[o], b = a.score_pre_b[o];
-      for (int k = 0; k < 2 * H; ++k) {
-        s += vp[k] * a.oq_embed_w[k * V + o];
-        g += vp[k] * a.gamma_pre_w[k * V + o];
-        b += vp[k] * a.score_pre_w[k * V + o];
-      }
-      emb[o] = mish_f(s);
-      gpre[o] = mish_f(g);
-      base[o] = b;
-    }
-    __syncthreads();
-    if (threadIdx.x < 14) {
-      float s = a.oq_out_b[threadIdx.x];
-      for (int k = 0; k < V; ++k) s += emb[k] * a.oq_out_w[k * 14 + threadIdx.x];
-      if (threadIdx.x == 0) out[kOffOutcomeLogits] = s, s_misc[0] = s;
-      if (threadIdx.x == 1) out[kOffOutcomeLogits + 1] = s, s_misc[1] = s;
-      if (threadIdx.x == 5) out[kOffErr2] = 4.0f / (1.0f + __expf(-s));
-    } else if (threadIdx.x == 64) {
-      float s = a.gamma_out_b[0];
-      for (int k = 0; k < V; ++k) s += gpre[k] * a.gamma_out_w[k];
-      out[kOffGamma] = s;
-      float sp = s > 20.0f ? s : log1pf(__expf(s));
-      s_misc[2] = fminf(sp, 10.0f);
-    } else if (threadIdx.x == 128) {
-      float s2[2] = {a.pass_b[0], a.pass_b[1]};
-      float so = a.opt_pass_b[0];
-      for (int k = 0; k < 2 * H; ++k) {
-        s2[0] += gp[k] * a.pass_w[k * 2];
-        s2[1] += gp[k] * a.pass_w[k * 2 + 1];
-        so += gp[k] * a.opt_pass_w[k];
-      }
-      s_pi[361] = s2[0] - 3.0f;
-      s_opt[361] = so - 3.0f;
-    }
-    __syncthreads();
-    // ---- per-location policy logits and ownership -----------------------------------
-    for (int i = threadIdx.x; i < kNLoc; i += 256) {
-      float pi = 0.0f, po = 0.0f, ow = 0.0f;
+    if (t < H) {
+      float s = hl[L::gd_b + t];
 #pragma unroll 8
-      for (int c = 0; c < H; ++c) {
-        const float p = mish_f(hp[(size_t)c * kNLoc + i] + gbias[c]);
-        pi += p * a.moves_w[c * 2];
-        po += p * a.opt_moves_w[c];
-        ow += hp[(size_t)(2 * H + c) * kNLoc + i] * a.own_w[c];
+      for (int k = 0; k < 2 * H; ++k) s += sc[L::gp + k] * hl[L::gd_w + k * H + t];
+      sc[L::gbias + t] = s;
+    } else if (t >= 64 && t < 64 + V) {
+      const int o = t - 64;
+      float s = hl[L::oq_embed_b + o], gm = hl[L::gamma_pre_b + o], b = hl[L::score_pre_b + o];
+#pragma unroll 8
+      for (int k = 0; k < 2 * H; ++k) {
+        const float x = sc[L::vp + k];
+        s += x * hl[L::oq_embed_w + k * V + o];
+        gm += x * hl[L::gamma_pre_w + k * V + o];
+        b += x * hl[L::score_pre_w + k * V + o];
       }
-      s_pi[i] = pi;
-      s_opt[i] = po;
-      out[kOffOwnership + i] = tanhf(ow);
-    }
-    // ---- score logits: 800 bins x V ---------------------------------------------------
-    for (int sidx = threadIdx.x; sidx < 800; sidx += 256) {
-      const float sc = 0.05f * (float)(sidx - 400) + 0.025f;
-      float s = a.score_out_b[0];
-      for (int k = 0; k < V; ++k) s += mish_f(base[k] + sc * a.score_pre_w[(2 * H) * V + k]) * a.score_out_w[k];
-      s_logits[sidx] = s_misc[2] * s;
+      sc[L::emb + o] = mish_f(s);
+      sc[L::gpre + o] = mish_f(gm);
+      sc[L::base + o] = b;
+    } else if (t == 192) {
+      float s0 = pass_b0, so = opt_pass_b;
+#pragma unroll 8
+      for (int k = 0; k < 2 * H; ++k) {
+        s0 += sc[L::gp + k] * hl[L::pass_w + k * 2];
+        so += sc[L::gp + k] * hl[L::opt_pass_w + k];
+      }
+      sc[L::pi + 361] = s0 - 3.0f;
+      sc[L::opt + 361] = so - 3.0f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 362; i += 256) {
-      out[kOffMoveLogits + i] = s_pi[i];
-      out[kOffOptLogits + i] = s_opt[i];
+    if (t < 14) {
+      float s = hl[L::oq_out_b + t];
+#pragma unroll 8
+      for (int k = 0; k < V; ++k) s += sc[L::emb + k] * hl[L::oq_out_w + k * 14 + t];
+      if (t < 2) sc[L::misc + t] = s;
+      if (live) {
+        if (t < 2) out[kOffOutcomeLogits + t] = s;
+        if (t == 5) out[kOffErr2] = 4.0f / (1.0f + __expf(-s));
+      }
+    } else if (t == 64) {
+      float s = gamma_out_b;
+#pragma unroll 8
+      for (int k = 0; k < V; ++k) s += sc[L::gpre + k] * hl[L::gamma_out_w + k];
+      if (live) out[kOffGamma] = s;
+      const float sp = s > 20.0f ? s : log1pf(__expf(s));
+      sc[L::misc + 2] = fminf(sp, 10.0f);
     }
-    for (int i = threadIdx.x; i < 800; i += 256) out[kOffScoreLogits + i] = s_logits[i];
-    softmax_block(s_pi, out + kOffMoveProbs, 362, red);
-    softmax_block(s_opt, out + kOffOptProbs, 362, red);
-    softmax_block(s_logits, out + kOffScoreProbs, 800, red);
-    if (threadIdx.x == 0) {
-      const float m = fmaxf(s_misc[0], s_misc[1]);
-      const float e0 = __expf(s_misc[0] - m), e1 = __expf(s_misc[1] - m);
-      out[kOffValueProbs] = e0 / (e0 + e1);
-      out[kOffValueProbs + 1] = e1 / (e0 + e1);
+    // ---- per-location policy logits and ownership (needs gbias only) ------------------
+    for (int i = t; i < kNLoc; i += 256) {
+      float pi = 0.0f, po = 0.0f, ow = 0.0f;
+      const int z = launder(0);   // keeps the LDS weight reads inside the location loop
+#pragma unroll
+      for (int c0 = 0; c0 < H; c0 += 8) {   // 16 loads in flight per round
+        float pv[8], vv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          pv[c] = hp[(size_t)(c0 + c) * kNLoc + i];
+          vv[c] = hp[(size_t)(2 * H + c0 + c) * kNLoc + i];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float p = mish_f(pv[c] + sc[L::gbias + z + c0 + c]);
+          pi += p * hl[L::moves_w + z + (c0 + c) * 2];
+          po += p * hl[L::opt_moves_w + z + c0 + c];
+          ow += vv[c] * hl[L::own_w + z + c0 + c];
+        }
+      }
+      sc[L::pi + i] = pi;
+      sc[L::opt + i] = po;
+      if (live) out[kOffOwnership + i] = tanhf(ow);
+    }
+    __syncthreads();   // misc[2] (gamma) ready
+    // ---- score logits: 800 bins x V ---------------------------------------------------
+    {
+      const float gam = sc[L::misc + 2];
+      for (int sidx = t; sidx < 800; sidx += 256) {
+        const float sv = 0.05f * (float)(sidx - 400) + 0.025f;
+        float s = score_out_b;
+        const int z = launder(0);   // keeps the LDS reads inside the bin loop
+#pragma unroll 8
+        for (int k = 0; k < V; ++k)
+          s += mish_f(sc[L::base + z + k] + sv * hl[L::score_pre_w + (2 * H) * V + z + k]) * hl[L::score_out_w + z + k];
+        sc[L::logits + sidx] = gam * s;
+      }
+    }
+    __syncthreads();
+    // ---- raw logits out + the three softmaxes, reductions fused ------------------------
+    float m3[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = t; i < 362; i += 256) {
+      const float p = sc[L::pi + i], o = sc[L::opt + i];
+      if (live) {
+        out[kOffMoveLogits + i] = p;
+        out[kOffOptLogits + i] = o;
+      }
+      m3[0] = fmaxf(m3[0], p);
+      m3[1] = fmaxf(m3[1], o);
+    }
+    for (int i = t; i < 800; i += 256) {
+      const float l = sc[L::logits + i];
+      if (live) out[kOffScoreLogits + i] = l;
+      m3[2] = fmaxf(m3[2], l);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) m3[r] = wave_max(m3[r]);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) sc[L::red + r * 4 + wid] = m3[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      m3[r] = fmaxf(fmaxf(sc[L::red + r * 4], sc[L::red + r * 4 + 1]),
+                    fmaxf(sc[L::red + r * 4 + 2], sc[L::red + r * 4 + 3]));
+    __syncthreads();   // red is rewritten below
+    float s3[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = t; i < 362; i += 256) {
+      const float e0 = __expf(sc[L::pi + i] - m3[0]), e1 = __expf(sc[L::opt + i] - m3[1]);
+      sc[L::pi + i] = e0;
+      sc[L::opt + i] = e1;
+      s3[0] += e0;
+      s3[1] += e1;
+    }
+    for (int i = t; i < 800; i += 256) {
+      const float e = __expf(sc[L::logits + i] - m3[2]);
+      sc[L::logits + i] = e;
+      s3[2] += e;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) s3[r] = wave_sum(s3[r]);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) sc[L::red + r * 4 + wid] = s3[r];
+    }
+    __syncthreads();
+    if (live) {
+      const float i0 = 1.0f / (sc[L::red + 0] + sc[L::red + 1] + sc[L::red + 2] + sc[L::red + 3]);
+      const float i1 = 1.0f / (sc[L::red + 4] + sc[L::red + 5] + sc[L::red + 6] + sc[L::red + 7]);
+      const float i2 = 1.0f / (sc[L::red + 8] + sc[L::red + 9] + sc[L::red + 10] + sc[L::red + 11]);
+      for (int i = t; i < 362; i += 256) {
+        out[kOffMoveProbs + i] = sc[L::pi + i] * i0;
+        out[kOffOptProbs + i] = sc[L::opt + i] * i1;
+      }
+      for (int i = t; i < 800; i += 256) out[kOffScoreProbs + i] = sc[L::logits + i] * i2;
+      if (t == 0) {
+        const float v0 = sc[L::misc], v1 = sc[L::misc + 1];
+        const float m = fmaxf(v0, v1);
+        const float e0 = __expf(v0 - m), e1 = __expf(v1 - m);
+        out[kOffValueProbs] = e0 / (e0 + e1);
+        out[kOffValueProbs + 1] = e1 / (e0 + e1);
+      }
     }
     __syncthreads();
   }
@@ -659,9 +788,27 @@ hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_heads(const HeadsArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((k_heads<32>), dim3(grid), dim3(256), 0, s, a);
+template <int V>
+static hipError_t launch_heads_t(const HeadsArgs& a, hipStream_t s) {
+  using L = HeadsLds<32, V>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = set_lds(k_heads<32, V>, L::bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = (a.npos + L::kGroups - 1) / L::kGroups;
+  hipLaunchKernelGGL((k_heads<32, V>), dim3(grid), dim3(1024), L::bytes, s, a);
   return hipGetLastError();
+}
+
+hipError_t launch_heads(const HeadsArgs& a, int grid, hipStream_t s) {
+  (void)grid;
+  if (a.V == 64) return launch_heads_t<64>(a, s);
+  if (a.V == 80) return launch_heads_t<80>(a, s);
+  if (a.V == 48) return launch_heads_t<48>(a, s);
+  if (a.V == 32) return launch_heads_t<32>(a, s);
+  return hipErrorInvalidValue;
 }
 
 const char* block_kernel_name(int C, int kind, int L) {

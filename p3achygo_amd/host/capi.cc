@@ -138,3 +138,46 @@ extern "C" int p3host_test_scripted_search(int n, int k, int* child_visits, floa
   *root_n = root->n;
   return (int)search.result().visits << 8;
 }
+
+// ---- TF recorder (tests mirror cc/recorder/__tests__/{tf_recorder,sel_mult}_test.cc) --------
+#include "tf_recorder.h"
+
+extern "C" {
+void* p3host_tfrec_new(const char* dir, int gen, const char* worker) { return new TfRecorder(dir, gen, worker); }
+void p3host_tfrec_free(void* r) { delete (TfRecorder*)r; }
+int p3host_tfrec_flush(void* r) { return ((TfRecorder*)r)->Flush(); }
+const char* p3host_tfrec_last_chunk(void* r) { return ((TfRecorder*)r)->last_chunk().c_str(); }
+// One finished game given as a move list (encoding of p3host_sgf_from_moves) plus per-move
+// record columns; null columns take the defaults of the reference tests' SimpleRecord.
+// stats rows: sampled_raw_policy, nn_q, mcts_q, nn_mcts_diff, v_outcome_stddev, prior_entropy,
+// nn_uncertainty, kld, pre_kld, sel_mult_modifier, sel_mult_modifier_weight, visit_count,
+// visit_count_pre.
+int p3host_tfrec_record(void* r, const int* moves, int n, float komi, const float* pi, const uint8_t* trainable,
+                        const float* root_q, const float* root_score, const float* kld,
+                        const uint32_t* value_dist, const float* stats) {
+  Game g(komi, true);
+  for (int i = 0; i < n; ++i) {
+    Color c = moves[i] > 0 ? kBlack : kWhite;
+    int idx = (moves[i] > 0 ? moves[i] : -moves[i]) - 1;
+    if (!g.PlayMove(MoveLoc(idx), c)) return -1;
+  }
+  g.WriteResult();
+  std::vector<MoveSearchRecord> infos(n);
+  for (int i = 0; i < n; ++i) {
+    MoveSearchRecord& m = infos[i];
+    for (int a = 0; a < kNumMoves; ++a) m.mcts_pi[a] = pi ? pi[i * kNumMoves + a] : 1.0f / kNumMoves;
+    m.move_trainable = trainable ? trainable[i] : 1;
+    m.root_q_outcome = root_q ? root_q[i] : 0.5f;
+    m.root_score = root_score ? root_score[i] : 0.0f;
+    m.kld = kld ? kld[i] : 0.0f;
+    if (value_dist) std::memcpy(m.mcts_value_dist, value_dist + i * kNumVBuckets, sizeof m.mcts_value_dist);
+    if (stats) {
+      const float* s = stats + i * 13;
+      m.move_stats = MoveSearchStats{s[0] != 0.0f, s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9], s[10], s[11], s[12]};
+    }
+  }
+  ((TfRecorder*)r)->RecordGame(Board(komi, true), g, std::move(infos));
+  return 0;
+}
+uint32_t p3host_crc32c(const void* p, size_t n) { return Crc32c(p, n); }
+}

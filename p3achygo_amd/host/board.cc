@@ -626,6 +626,9 @@ Game::Game(float komi, bool prohibit_pass_alive) : board_(komi, prohibit_pass_al
   moves_.assign(kMoveOffset, Move{kEmpty, kNoopLoc});
 }
 
+Game::Game(const Board& board, const Move last_moves[5], int init_mv_num)
+    : board_(board), moves_(last_moves, last_moves + kMoveOffset), init_mv_num_(init_mv_num) {}
+
 bool Game::PlayMove(Loc loc, Color color) {
   bool ok = MoveOk(board_.PlayMove(loc, color));
   if (ok) moves_.push_back(Move{color, loc});

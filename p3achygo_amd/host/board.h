@@ -112,6 +112,10 @@ class Board {
   void PlaceRaw(Loc loc, Color color);
 
   bool SamePosition(const Board& o) const { return stones_ == o.stones_; }
+  bool IsEmpty() const {   // board.h:305-308
+    for (Color c : stones_) if (c != kEmpty) return false;
+    return true;
+  }
 
  private:
   friend struct LadderSolver;
@@ -154,6 +158,9 @@ class Game {
     Grid ownership{};
   };
   explicit Game(float komi = 7.5f, bool prohibit_pass_alive = true);
+  // restart from a stored position: game.cc:9-17 (moves_ = the five last moves)
+  Game(const Board& board, const Move last_moves[5], int init_mv_num);
+  int init_mv_num() const { return init_mv_num_; }
   const Board& board() const { return board_; }
   Board& mutable_board() { return board_; }
   int num_moves() const { return (int)moves_.size() - kMoveOffset; }
@@ -171,6 +178,7 @@ class Game {
   Board board_;
   std::vector<Move> moves_;
   Result result_;
+  int init_mv_num_ = 0;
 };
 
 

@@ -181,3 +181,100 @@ int p3host_tfrec_record(void* r, const int* moves, int n, float komi, const floa
 }
 uint32_t p3host_crc32c(const void* p, size_t n) { return Crc32c(p, n); }
 }
+
+// ---- fork manager / init-state / move-selection tests ----------------------------------------
+#include "selfplay_policy.h"
+
+extern "C" {
+// Plays `n_moves` scripted legal moves (first empty point scanning from a seed-dependent
+// offset), calling MaybeFork before each; network evaluations are answered by a scripted
+// result whose policy is uniform over the board, win probability `p_win` and a one-hot score
+// distribution at margin `score` (bin index score + 400, so E[score] = score + 0.5).
+// kind: index into (early, late, t1, t2, random, regret, uniform) given probability 1.
+// Outputs the InitState that reached the buffer (if any): out[0]=#states added,
+// [1]=move_num, [2]=colour to move, [3]=first_move_behavior, [4]=#stones on its board,
+// [5]=#evaluations requested, [6]=fork move number, [7]=kind; komi_out = its komi; last5 =
+// encoded last moves (i*19+j, pass 361, noop -20).
+int p3host_test_fork(int kind, int n_moves, uint64_t seed, float p_win, int score, int* out, float* komi_out,
+                     int* last5, int8_t* board_out) {
+  ForkParams fp;
+  fp.early = fp.late = fp.t1 = fp.t2 = fp.random = fp.regret = fp.uniform = 0.0f;
+  float* slots[7] = {&fp.early, &fp.late, &fp.t1, &fp.t2, &fp.random, &fp.regret, &fp.uniform};
+  *slots[kind] = 1.0f;
+  ReuseBuffer buf(seed);
+  Probability prob(seed);
+  ForkManager fm(fp, &buf, prob, false);
+  Game g(7.5f, true);
+  Color c = kBlack;
+  p3hip_result r;
+  std::memset(&r, 0, sizeof r);
+  for (int a = 0; a < kNumMoves; ++a) { r.move_logits[a] = 0; r.move_probs[a] = 1.0f / kNumMoves; r.opt_move_probs[a] = 1.0f / kNumMoves; }
+  r.value_probs[0] = 1 - p_win; r.value_probs[1] = p_win;
+  r.score_probs[score + 400] = 1.0f;
+  int evals = 0;
+  for (int m = 0; m < n_moves && !g.IsGameOver(); ++m) {
+    Loc mv = kPassLoc;
+    for (int t = 0; t < kNumLocs; ++t) {
+      int idx = (int)((seed * 31 + m * 7 + t * 13) % kNumLocs);
+      if (g.IsValidMove(AsLoc(idx), c)) { mv = AsLoc(idx); break; }
+    }
+    ForkManager::MoveData md{&g.board(), c, mv, 0.1f, 0.2f, 3.0f, true};
+    if (fm.MaybeFork(g, md, prob)) {
+      Position pos;
+      Color ec;
+      while (fm.NextEval(&pos, &ec)) { ++evals; fm.Deliver(r); }
+    }
+    g.PlayMove(mv, c);
+    c = Opp(c);
+  }
+  g.WriteResult();
+  fm.FinalizeGame(g, prob);
+  out[0] = (int)buf.added();
+  out[5] = evals;
+  out[6] = fm.fork_move_num();
+  out[7] = (int)fm.kind();
+  if (auto s = buf.Get()) {
+    out[1] = s->move_num;
+    out[2] = s->color_to_move;
+    out[3] = (int)s->first_move_behavior;
+    int stones = 0;
+    for (int i = 0; i < kNumLocs; ++i) { stones += s->board.at(i) != kEmpty; if (board_out) board_out[i] = s->board.at(i); }
+    out[4] = stones;
+    *komi_out = s->board.komi();
+    for (int i = 0; i < 5; ++i) last5[i] = TfRecorder::EncodeLoc16(s->last_moves[i].loc);
+  }
+  return 0;
+}
+
+// GetInitState statistics over `n` draws with an empty buffer: counts of handicap games and
+// the histogram of komi*2 (index komi*2, 0..63) for the non-handicap ones.
+void p3host_test_init_states(uint64_t seed, int n, int* handicap_count, int* komi2_hist, int* handicap_stones) {
+  Probability prob(seed);
+  ReuseBuffer buf(seed);
+  *handicap_count = 0;
+  for (int i = 0; i < 64; ++i) komi2_hist[i] = 0;
+  for (int i = 0; i < 3; ++i) handicap_stones[i] = 0;
+  for (int i = 0; i < n; ++i) {
+    InitState s = GetInitState(prob, &buf, 0.5f);
+    if (s.kind == InitState::Kind::kHandicap) {
+      ++*handicap_count;
+      int stones = 0;
+      for (int p = 0; p < kNumLocs; ++p) stones += s.board.at(p) != kEmpty;
+      if (stones >= 2 && stones <= 4 && s.color_to_move == kWhite && s.board.komi() == (stones - 2) * 14 + 20.5f) ++handicap_stones[stones - 2];
+    } else {
+      int k2 = (int)std::lround(s.board.komi() * 2);
+      if (k2 >= 0 && k2 < 64) ++komi2_hist[k2];
+    }
+  }
+}
+
+// MoveSelManager::Compute with the default calibration and the self-play flags
+// (kNnMctsBonus | kKldPenalty); out = modifier, bonus, penalty, q_adjust, kld_penalty, nn_mcts_bonus
+void p3host_test_move_sel(int n_pre, float std_dev, float pre_kld, float nn_mcts_diff, float q, float scale, float* out) {
+  SelMultCalibration cal;
+  MoveSelManager m(kNnMctsBonus | kKldPenalty, cal);
+  MoveSelResult r = m.Compute(n_pre, std_dev, pre_kld, nn_mcts_diff, q, scale);
+  out[0] = r.modifier; out[1] = r.sel_bonus; out[2] = r.sel_penalty; out[3] = r.sel_q_adjust;
+  out[4] = r.sel_kld_penalty; out[5] = r.sel_nn_mcts_bonus;
+}
+}

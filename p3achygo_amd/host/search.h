@@ -189,6 +189,34 @@ inline void EvaluateTerminal(const Scores& s, TreeNode* node, Color c, Color roo
 }
 
 // ---- non-root PUCT (search_policy.h:159-368, IdentityQ / IdentityN) -----------------
+// Public ComputeImprovedPolicy(node, n) / ComputeKLD of the reference (gumbel.cc:172-204),
+// used by the self-play loop for its pre-/post-search KL statistics.
+inline float VMixedOf(const TreeNode* node) {   // gumbel.cc:68-87
+  if (SumChildrenN(node) == 0) return node->init_util_est;
+  double wq = 0, vp = 0;
+  for (const ChildEdge& e : node->children)
+    if (e.visits > 0) { wq += node->move_probs[e.action] * -e.node->v; vp += node->move_probs[e.action]; }
+  const double iq = wq * SumChildrenN(node) / vp + node->init_util_est;
+  return (float)(iq / (1 + SumChildrenN(node)));
+}
+inline void ComputeImprovedPolicyN(const TreeNode* node, int n, float* out) {
+  auto q_norm = [](float q) { return (q + 1.5f) / 3.0f; };
+  const float v_mix = q_norm(VMixedOf(node));
+  const float scale = n <= 0 ? 0.0f : 2 * std::log((float)n);
+  float logits[kNumMoves];
+  for (int a = 0; a < kNumMoves; ++a) {
+    const float q = node->child_visits(a) > 0 ? q_norm(Q(node, a)) : v_mix;
+    logits[a] = node->move_logits[a] + (50 + scale) * q;   // QTransform, kVisit = 50, kValueScale = 1
+  }
+  SoftmaxN(logits, out, kNumMoves);
+}
+inline float ComputeKLD(const float* target, const float* prior) {
+  double kld = 0;
+  for (int i = 0; i < kNumMoves; ++i)
+    if (target[i] != 0.0f) kld += target[i] * std::log(target[i] / (prior[i] + 1e-10));
+  return (float)kld;
+}
+
 struct PuctParams {
   float c_puct = 1.0f, c_puct_visit_scaling = 0.45f;
   bool enable_var_scaling = false;

@@ -28,9 +28,13 @@
 #include <thread>
 #include <vector>
 
+#include <sys/stat.h>
+
 #include "features.h"
 #include "recorder.h"
 #include "search.h"
+#include "selfplay_policy.h"
+#include "tf_recorder.h"
 
 namespace p3 {
 
@@ -101,21 +105,64 @@ struct HipEvaluator final : Evaluator {
 };
 
 // ---- one game ----------------------------------------------------------------------------
-struct SelfPlayConfig {       // SPConfig, cc/selfplay/self_play_thread.h:38-61 (subset)
+// Buffers finished games for both recorders (recorder::GameRecorder, game_recorder.cc:68-175):
+// SGF lines only for games that started on an empty board, training examples for all.
+class GameRecorder {
+ public:
+  GameRecorder(const std::string& path, int gen, const std::string& worker_id, int flush_interval)
+      : sgf_(path + "/sgf", gen, worker_id), tf_(path + "/chunks", gen, worker_id), flush_interval_(flush_interval) {}
+  void RecordGame(const Board& init_board, const Game& game, std::vector<MoveSearchRecord> infos) {
+    if (init_board.IsEmpty()) sgf_.RecordGame(SgfGameString(game, "p3achygo", "p3achygo"));   // game_recorder.cc:20,101-108
+    std::lock_guard<std::mutex> l(mu_);
+    tf_.RecordGame(init_board, game, std::move(infos));
+    ++buffered_;
+  }
+  bool ShouldFlush() {
+    std::lock_guard<std::mutex> l(mu_);
+    return buffered_ >= flush_interval_;
+  }
+  void Flush() {
+    sgf_.Flush();
+    std::lock_guard<std::mutex> l(mu_);
+    examples_ += tf_.Flush();
+    buffered_ = 0;
+  }
+  long examples() const { return examples_; }
+
+ private:
+  SgfRecorder sgf_;
+  TfRecorder tf_;
+  std::mutex mu_;
+  int flush_interval_, buffered_ = 0;
+  long examples_ = 0;
+};
+
+struct SelfPlayConfig {       // SPConfig, cc/selfplay/self_play_thread.h:38-61
   int selected_n = 128, selected_k = 8;   // --gumbel_selected_{n,k}  selfplay/main.cc:40-43
   int default_n = 32, default_k = 5;      // --gumbel_default_{n,k}   selfplay/main.cc:44-47
   int max_moves = 600;                    // --max_moves
   int nonroot_var_scale_prior_visits = 10;
+  float use_seen_state_prob = 0.5f;       // --use_seen_state_prob     main.cc:48-50
+  float sel_mult_base = 0.0f, sel_mult_scale_factor = 1.0f;   // main.cc:51-57
+  ForkParams fork_params = ForkParams::ForReuse(0.5f);        // main.cc:191-193
+  SelMultCalibration calibration;
+  // false: every game starts from the empty board at `komi`, no forks (plumbing tests)
+  bool init_state_sampling = true;
   float komi = 7.5f;
   bool raw_policy_opening = true;
   int cache_entries_per_game = 64;   // 0 disables the evaluation cache
   bool enable_puct_fast_search = true;
-  SgfRecorder* sgf = nullptr;        // optional: finished games are serialized here
+  ReuseBuffer* reuse = nullptr;      // shared by the games of one process (main.cc:186)
+  GameRecorder* recorder = nullptr;  // optional
 };
 
 constexpr int kMaxNumRawPolicyMoves = 30;              // self_play_thread.cc:45
 constexpr float kMoveSelectedForTrainingProb = 0.25f;  // :62
 constexpr int kComputePAMoveNums[] = {200, 250, 300, 350, 400};   // :56
+constexpr float kOverSearchNodeProb = 0.15f;           // :65
+constexpr float kDownBadThreshold = -0.90f;            // :68
+constexpr int kNumDownBadMovesThreshold = 5;           // :71
+constexpr float kPuctFastSearchProb = 0.25f;           // :74
 
 struct GameStats {
   long moves = 0, games = 0, evals = 0, black_wins = 0, cache_hits = 0;
@@ -168,23 +215,29 @@ class EvalCache {
 class GameRunner {
  public:
   GameRunner(const SelfPlayConfig& cfg, uint64_t seed)
-      : cfg_(cfg), prob_(seed), seed_(seed), cache_(cfg.cache_entries_per_game) { NewGame(); }
+      : cfg_(cfg), prob_(seed), seed_(seed), cache_(cfg.cache_entries_per_game),
+        move_sel_(kNnMctsBonus | kKldPenalty, cfg.calibration) {   // self_play_thread.cc:315-316
+    NewGame();
+  }
 
   // Advances this game until it needs a network evaluation; writes the features of the
   // position to evaluate into *f.
   void AdvanceToEval(p3hip_features* f) {
     for (;;) {
-      if (search_.Step() == GumbelSearch::Status::kNeedEval) {
-        pending_key_ = EvalCache::MakeKey(*search_.eval_game(), search_.eval_color());
-        if (const p3hip_result* hit = cache_.Find(pending_key_)) {   // nn_interface.cc:112-118
-          ++stats_.cache_hits;
-          search_.Resume(*hit);
+      if (forking_) {   // the fork manager's candidate evaluations ride in the same batches
+        Color c;
+        if (!fork_->NextEval(&side_pos_, &c)) {
+          forking_ = false;
+          PlayMove();
           continue;
         }
-        sym_ = RandomSymmetry(prob_.prng());   // nn_interface.cc:123
-        FillFeatures(*search_.eval_game(), search_.eval_color(), sym_, f);
-        ++stats_.evals;
-        return;
+        side_pending_ = true;
+        if (RequestEval(side_pos_, c, f)) return;
+        continue;
+      }
+      if (search_.Step() == GumbelSearch::Status::kNeedEval) {
+        if (RequestEval(*search_.eval_game(), search_.eval_color(), f)) return;
+        continue;
       }
       FinishMove();
     }
@@ -192,7 +245,7 @@ class GameRunner {
   void DeliverResult(p3hip_result& r) {
     UnapplySymmetry(sym_, &r);   // nn_interface.h:263-288
     cache_.Insert(pending_key_, r);   // nn_interface.cc:130
-    search_.Resume(r);
+    Resume(r);
   }
   const GameStats& stats() const { return stats_; }
   const Game& game() const { return *game_; }
@@ -200,15 +253,52 @@ class GameRunner {
   const Game::Result& last_result() const { return last_result_; }
 
  private:
-  void NewGame() {
-    game_.reset(new Game(cfg_.komi, true));
+  // true: *f holds a position for the engine; false: served from the cache
+  bool RequestEval(const Position& pos, Color c, p3hip_features* f) {
+    pending_key_ = EvalCache::MakeKey(pos, c);
+    if (const p3hip_result* hit = cache_.Find(pending_key_)) {   // nn_interface.cc:112-118
+      ++stats_.cache_hits;
+      Resume(*hit);
+      return false;
+    }
+    sym_ = RandomSymmetry(prob_.prng());   // nn_interface.cc:123
+    FillFeatures(pos, c, sym_, f);
+    ++stats_.evals;
+    return true;
+  }
+  void Resume(const p3hip_result& r) {
+    if (side_pending_) {
+      side_pending_ = false;
+      fork_->Deliver(r);
+    } else {
+      search_.Resume(r);
+    }
+  }
+
+  void NewGame() {   // self_play_thread.cc:319-426
+    InitState init;
+    if (cfg_.init_state_sampling) {
+      init = GetInitState(prob_, cfg_.reuse, cfg_.use_seen_state_prob);
+    } else {
+      init.board = Board(cfg_.komi, true);
+    }
+    force_full_search_first_move_ = init.first_move_behavior == FirstMoveBehavior::kForceFullSearch;
+    const bool disable_sampling = init.first_move_behavior != FirstMoveBehavior::kSample;
+    const bool is_fresh_game = init.kind == InitState::Kind::kEmpty || init.kind == InitState::Kind::kBook ||
+                               init.kind == InitState::Kind::kHandicap;
+    init_board_ = init.board;
+    game_.reset(new Game(init.board, init.last_moves, init.move_num));
+    color_ = init.color_to_move;
     pool_.Clear();
-    color_ = kBlack;
     root_ = pool_.Create();
-    // per-game draws, self_play_thread.cc:364-368,413-423
-    const int max_raw = kMaxNumRawPolicyMoves;
-    num_moves_raw_policy_ = cfg_.raw_policy_opening ? RandRange(prob_.prng(), 0, max_raw) : 0;
-    use_puct_fast_search_ = prob_.Uniform() < 0.25f && cfg_.enable_puct_fast_search;   // kPuctFastSearchProb, :74
+    move_infos_.clear();
+    num_consecutive_down_bad_moves_ = 0;
+    (void)prob_.Uniform();   // log_mcts_trees draw, kLogFullTreeProb = 0 (:353)
+    const int max_raw = (int)std::round(kMaxNumRawPolicyMoves * std::pow(0.5f, init.move_num / 40.0f));
+    num_moves_raw_policy_ = 0;
+    if (cfg_.raw_policy_opening && !disable_sampling && max_raw > 0 && prob_.Uniform() < 1.0f)   // kOpeningExploreProb
+      num_moves_raw_policy_ = RandRange(prob_.prng(), 0, max_raw);
+    use_puct_fast_search_ = prob_.Uniform() < kPuctFastSearchProb && cfg_.enable_puct_fast_search;
     fast_move_noise_scaling_ = prob_.Uniform() / 1.4f;
     {
       int num_rounds = (int)std::log2((double)cfg_.default_k);
@@ -216,21 +306,66 @@ class GameRunner {
       fast_move_gumbel_k_ = RandRange(prob_.prng(), min_k, cfg_.default_k + 1);
     }
     fast_move_root_fpu_ = prob_.Uniform() * 0.1f;   // :424
+    fork_.reset();
+    if (cfg_.init_state_sampling && cfg_.reuse)
+      fork_.reset(new ForkManager(cfg_.fork_params, cfg_.reuse, prob_, /*started_from_forced_search=*/!is_fresh_game));
+    forking_ = side_pending_ = false;
     cache_.Clear();
     BeginSearch();
   }
 
-  void BeginSearch() {
+  void BeginSearch() {   // self_play_thread.cc:429-611
     const bool sampling_raw_policy = game_->num_moves() < num_moves_raw_policy_;
-    const float select_prob = sampling_raw_policy ? 0.0f : kMoveSelectedForTrainingProb;
-    const bool selected = prob_.Uniform() < select_prob;   // self_play_thread.cc:536-537
-    (void)prob_.Uniform();                                  // over-search draw (dead code, :538-540)
+    const bool is_either_down_bad = num_consecutive_down_bad_moves_ >= kNumDownBadMovesThreshold;
+    float down_bad_coeff = 1.0f;
+    {
+      const float root_v = VOutcome(root_);
+      if (!(root_v > kDownBadThreshold && root_v < -kDownBadThreshold))
+        down_bad_coeff = (1.0f - std::abs(root_v)) / (1.0f - std::abs(kDownBadThreshold));
+    }
+    // pre-search statistics (from tree reuse)
+    pre_.sampling_raw_policy = sampling_raw_policy;
+    const float qz_nn = root_->init_outcome_est;
+    pre_.n_pre = root_->n;
+    pre_.q_pre = V(root_);
+    const float qz_pre = VOutcome(root_);
+    pre_.var_pre = pre_.n_pre < 3 ? 0.0f : root_->v_outcome_var;
+    pre_.pre_kld = 0.0f;
+    if (root_->n >= 1) {
+      float pi[kNumMoves];
+      ComputeImprovedPolicyN(root_, 0, pi);
+      pre_.pre_kld = ComputeKLD(pi, root_->move_probs);
+    }
+    const float q_canonical = qz_pre == 0.0f ? qz_nn : qz_pre;
+    pre_.nn_mcts_diff_pre = pre_.n_pre > 0 ? std::abs(qz_nn - pre_.q_pre) : 0.0f;
+    const MoveSelResult sel = move_sel_.Compute(pre_.n_pre, std::sqrt(pre_.var_pre), pre_.pre_kld, pre_.nn_mcts_diff_pre,
+                                                q_canonical, cfg_.sel_mult_scale_factor);
+    pre_.sel_mult_modifier = sampling_raw_policy ? 1.0f : sel.modifier;
+    const float sel_mult = cfg_.sel_mult_base > 0.0f ? cfg_.sel_mult_base * pre_.sel_mult_modifier : 1.0f;
+    float select_move_prob = 0.0f;
+    pre_.select_move_prob_base = 0.0f;
+    if (!sampling_raw_policy) {
+      pre_.select_move_prob_base = is_either_down_bad ? down_bad_coeff * down_bad_coeff * kMoveSelectedForTrainingProb
+                                                      : kMoveSelectedForTrainingProb;
+      select_move_prob = pre_.select_move_prob_base * sel_mult;
+    }
+    int train_n = cfg_.selected_n, train_k = cfg_.selected_k;   // trainable_gumbel_params, :526-537
+    if (is_either_down_bad) {
+      train_n = (int)((1.0f - down_bad_coeff) * cfg_.default_n + down_bad_coeff * cfg_.selected_n);
+      train_k = cfg_.default_k;
+    }
+    const bool force_first_move = force_full_search_first_move_ && game_->num_moves() == 0;
+    const bool selected = force_first_move || prob_.Uniform() < select_move_prob;   // :541-542
+    (void)prob_.Uniform();                                  // over-search draw (`&& false`, :543-545)
+    pre_.selected = selected;
     GumbelParams p;
     p.nonroot_var_scale_prior_visits = cfg_.nonroot_var_scale_prior_visits;
-    if (sampling_raw_policy) {
+    if (force_first_move) {
+      p.n = cfg_.selected_n; p.k = cfg_.selected_k;
+    } else if (sampling_raw_policy) {
       p.n = 1; p.k = 1;
     } else if (selected) {
-      p.n = cfg_.selected_n; p.k = cfg_.selected_k;
+      p.n = train_n; p.k = train_k;
     } else {
       p.n = cfg_.default_n; p.k = fast_move_gumbel_k_; p.noise_scaling = fast_move_noise_scaling_;
     }
@@ -250,9 +385,56 @@ class GameRunner {
     search_.Begin(game_.get(), &pool_, root_, color_, p, &prob_);
   }
 
-  void FinishMove() {
+  void FinishMove() {   // self_play_thread.cc:614-690
     const GumbelResult& res = search_.result();
-    const Loc move = res.mcts_move;
+    move_ = res.mcts_move;
+    const float root_q_outcome = VOutcome(root_);
+    if (cfg_.recorder) {
+      MoveSearchRecord mi;
+      std::memcpy(mi.mcts_pi, res.pi_improved, sizeof mi.mcts_pi);
+      mi.move_trainable = pre_.selected;
+      mi.root_q_outcome = root_q_outcome;
+      mi.root_score = root_->score;
+      mi.kld = res.kld;
+      std::memcpy(mi.mcts_value_dist, root_->v_categorical, sizeof mi.mcts_value_dist);
+      MoveSearchStats& st = mi.move_stats;   // :654-669 (visit_count is never set there: stays 0)
+      st.sampled_raw_policy = pre_.sampling_raw_policy;
+      st.nn_q = root_->init_util_est;
+      st.mcts_q = pre_.q_pre;
+      st.nn_mcts_diff = pre_.nn_mcts_diff_pre;
+      st.v_outcome_stddev = std::sqrt(pre_.var_pre);
+      float ent = 0;
+      for (int a = 0; a < kNumMoves; ++a)
+        if (root_->move_probs[a] > 0.0f) ent -= root_->move_probs[a] * std::log(root_->move_probs[a]);
+      st.prior_entropy = ent;
+      st.nn_uncertainty = root_->v_err;
+      st.kld = 0.0f;
+      if (root_->n >= 1) {
+        float pi[kNumMoves];
+        ComputeImprovedPolicyN(root_, 0, pi);
+        st.kld = ComputeKLD(pi, root_->move_probs);   // post_kld
+      }
+      st.pre_kld = pre_.pre_kld;
+      st.sel_mult_modifier = pre_.sel_mult_modifier;
+      st.sel_mult_modifier_weight = pre_.select_move_prob_base / kMoveSelectedForTrainingProb;
+      st.visit_count_pre = (float)pre_.n_pre;
+      move_infos_.push_back(mi);
+    }
+    if (-std::abs(root_q_outcome) < kDownBadThreshold) ++num_consecutive_down_bad_moves_;
+    else num_consecutive_down_bad_moves_ = 0;
+    if (fork_) {   // fork before playing the move (:681-688)
+      ForkManager::MoveData md{&game_->board(), color_, move_, root_->init_util_est, V(root_), root_->score,
+                               root_->child_visits(MoveIdx(move_)) != 0};
+      if (fork_->MaybeFork(*game_, md, prob_)) {
+        forking_ = true;
+        return;
+      }
+    }
+    PlayMove();
+  }
+
+  void PlayMove() {   // self_play_thread.cc:690-722, 900-912
+    const Loc move = move_;
     game_->PlayMove(move, color_);
     ++stats_.moves;
     for (int m : kComputePAMoveNums)
@@ -268,7 +450,8 @@ class GameRunner {
       if (game_->result().winner == kBlack) ++stats_.black_wins;
       last_result_ = game_->result();
       last_moves_ = game_->moves();
-      if (cfg_.sgf) cfg_.sgf->RecordGame(SgfGameString(*game_, "p3achygo", "p3achygo"));   // game_recorder.cc:20,108
+      if (fork_) fork_->FinalizeGame(*game_, prob_);
+      if (cfg_.recorder) cfg_.recorder->RecordGame(init_board_, *game_, std::move(move_infos_));
       NewGame();
       return;
     }
@@ -279,19 +462,33 @@ class GameRunner {
     BeginSearch();
   }
 
+  struct PreSearch {
+    bool sampling_raw_policy = false, selected = false;
+    int n_pre = 0;
+    float q_pre = 0, var_pre = 0, pre_kld = 0, nn_mcts_diff_pre = 0, sel_mult_modifier = 1, select_move_prob_base = 0;
+  };
+
   SelfPlayConfig cfg_;
   Probability prob_;
   uint64_t seed_;
   std::unique_ptr<Game> game_;
+  Board init_board_;
   NodePool pool_;
   TreeNode* root_ = nullptr;
   Color color_ = kBlack;
+  Loc move_ = kNoopLoc;
   GumbelSearch search_;
   Symmetry sym_ = kIdentity;
-  int num_moves_raw_policy_ = 0, fast_move_gumbel_k_ = 4;
+  int num_moves_raw_policy_ = 0, fast_move_gumbel_k_ = 4, num_consecutive_down_bad_moves_ = 0;
   float fast_move_noise_scaling_ = 1.0f, fast_move_root_fpu_ = 0.0f;
-  bool use_puct_fast_search_ = false;
+  bool use_puct_fast_search_ = false, force_full_search_first_move_ = false;
+  bool forking_ = false, side_pending_ = false;
+  std::unique_ptr<ForkManager> fork_;
+  Position side_pos_;
+  PreSearch pre_;
+  std::vector<MoveSearchRecord> move_infos_;
   EvalCache cache_;
+  MoveSelManager move_sel_;
   EvalCache::Key pending_key_{};
   GameStats stats_;
   Game::Result last_result_;
@@ -381,11 +578,29 @@ using namespace p3;
 namespace {
 std::string g_rec_dir, g_rec_worker = "0";
 int g_rec_gen = 0, g_rec_flush_interval = 128;   // --flush_interval, selfplay/main.cc:35
+bool g_init_state_sampling = true;
+float g_use_seen_state_prob = 0.5f, g_sel_mult_base = 0.0f, g_sel_mult_scale = 1.0f;
+long g_last_reuse_added = 0, g_last_examples = 0;
 }
 
 extern "C" {
 
-// Enables SGF recording for subsequent p3host_selfplay_run calls (dir == "" disables).
+// Game-loop policy of subsequent p3host_selfplay_run calls: init_state_sampling = 0 plays
+// every game from the empty board at komi 7.5 without forks (plumbing tests); otherwise the
+// reference defaults (selfplay/main.cc:48-57) unless overridden here.
+void p3host_selfplay_set_policy(int init_state_sampling, float use_seen_state_prob, float sel_mult_base,
+                                float sel_mult_scale_factor) {
+  g_init_state_sampling = init_state_sampling != 0;
+  g_use_seen_state_prob = use_seen_state_prob;
+  g_sel_mult_base = sel_mult_base;
+  g_sel_mult_scale = sel_mult_scale_factor;
+}
+// reuse-buffer insertions and training examples written by the last p3host_selfplay_run
+long p3host_selfplay_last_reuse_added() { return g_last_reuse_added; }
+long p3host_selfplay_last_examples() { return g_last_examples; }
+
+// Enables game recording for subsequent p3host_selfplay_run calls (dir == "" disables):
+// <dir>/sgf and <dir>/chunks as in selfplay/main.cc:157-158.
 void p3host_selfplay_set_recorder(const char* dir, int gen, const char* worker_id, int flush_interval) {
   g_rec_dir = dir ? dir : "";
   g_rec_gen = gen;
@@ -431,10 +646,19 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   cfg.default_n = default_n; cfg.default_k = default_k;
   cfg.selected_n = selected_n; cfg.selected_k = selected_k;
   cfg.max_moves = max_moves;
-  std::unique_ptr<SgfRecorder> sgf;
+  cfg.init_state_sampling = g_init_state_sampling;
+  cfg.use_seen_state_prob = g_use_seen_state_prob;
+  cfg.sel_mult_base = g_sel_mult_base;
+  cfg.sel_mult_scale_factor = g_sel_mult_scale;
+  cfg.fork_params = ForkParams::ForReuse(g_use_seen_state_prob);
+  auto reuse = std::make_unique<ReuseBuffer>(seed ^ 0x676f6578706c6f69ull);
+  cfg.reuse = reuse.get();
+  std::unique_ptr<GameRecorder> recorder;
   if (!g_rec_dir.empty()) {
-    sgf.reset(new SgfRecorder(g_rec_dir, g_rec_gen, g_rec_worker));
-    cfg.sgf = sgf.get();
+    ::mkdir((g_rec_dir + "/sgf").c_str(), 0755);
+    ::mkdir((g_rec_dir + "/chunks").c_str(), 0755);
+    recorder.reset(new GameRecorder(g_rec_dir, g_rec_gen, g_rec_worker, g_rec_flush_interval));
+    cfg.recorder = recorder.get();
   }
   Half halves[2];
   const bool use_null = !engine_lib || !engine_lib[0];
@@ -538,7 +762,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
       request_run(h);
     }
     if (rc) break;
-    if (sgf && sgf->buffered() >= g_rec_flush_interval) sgf->Flush();
+    if (recorder && recorder->ShouldFlush()) recorder->Flush();
     ++iter;
     if (!measuring && iter >= warmup_batches) {
       totals(base);
@@ -560,7 +784,9 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     H.cv.notify_all();
     H.gpu.join();
   }
-  if (sgf) sgf->Flush();
+  if (recorder) recorder->Flush();
+  g_last_reuse_added = reuse->added();
+  g_last_examples = recorder ? recorder->examples() : 0;
   if (out) {
     GameStats t;
     totals(t);
@@ -586,6 +812,7 @@ int p3host_selfplay_one_game(const char* engine_lib, const char* weights, int de
   cfg.default_n = default_n; cfg.default_k = default_k;
   cfg.selected_n = default_n; cfg.selected_k = default_k;
   cfg.max_moves = max_moves;
+  cfg.init_state_sampling = false;   // one empty-board game at komi 7.5
   std::unique_ptr<Evaluator> ev;
   if (!engine_lib || !engine_lib[0]) {
     ev.reset(new NullEvaluator());

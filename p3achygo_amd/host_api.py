@@ -173,8 +173,25 @@ def selfplay_one_game(weights: str | None, default_n: int, default_k: int, max_m
     return mv[:n].copy(), b.value, w.value, ev.value
 
 
+def set_policy(init_state_sampling: bool = True, use_seen_state_prob: float = 0.5, sel_mult_base: float = 0.0,
+               sel_mult_scale_factor: float = 1.0) -> None:
+    """Game-loop policy of subsequent selfplay_run calls (reference defaults, selfplay/main.cc:48-57);
+    init_state_sampling=False: every game from the empty board at komi 7.5, no forks."""
+    L = lib()
+    L.p3host_selfplay_set_policy.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float]
+    L.p3host_selfplay_set_policy(int(init_state_sampling), use_seen_state_prob, sel_mult_base, sel_mult_scale_factor)
+
+
+def last_run_counters():
+    """(reuse-buffer insertions, training examples written) of the last selfplay_run."""
+    L = lib()
+    L.p3host_selfplay_last_reuse_added.restype = C.c_long
+    L.p3host_selfplay_last_examples.restype = C.c_long
+    return L.p3host_selfplay_last_reuse_added(), L.p3host_selfplay_last_examples()
+
+
 def set_recorder(directory: str, gen: int = 0, worker_id: str = "0", flush_interval: int = 128) -> None:
-    """SGF recording for subsequent selfplay_run calls ('' disables)."""
+    """Game recording (<dir>/sgf, <dir>/chunks) for subsequent selfplay_run calls ('' disables)."""
     L = lib()
     L.p3host_selfplay_set_recorder.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     L.p3host_selfplay_set_recorder(directory.encode(), gen, worker_id.encode(), flush_interval)

@@ -157,9 +157,10 @@ def test_sgf_golden_strings(host):
     assert host.sgf_from_moves([_mv(1, 3, 3), 362 * -1]) .endswith(";B[dd];W[])")   # pass = empty value
 
 
-def test_sgf_recorder_files(host, tmp_path):
-    """Batch files follow cc/data/filename_format.h:27-31: gen%03d_b%03d_g%03d_%s.sgf with one
-    game per line and a matching .done file (sgf_recorder.cc:266-326)."""
+def test_game_recorder_files(host, tmp_path):
+    """<dir>/sgf batch files follow cc/data/filename_format.h:27-31 (gen%03d_b%03d_g%03d_%s.sgf,
+    one game per line, matching .done; only games that started on an empty board:
+    game_recorder.cc:101-108); <dir>/chunks holds the training chunks and their side files."""
     import os
     import re
     host.set_recorder(str(tmp_path), gen=7, worker_id="w3", flush_interval=4)
@@ -168,17 +169,167 @@ def test_sgf_recorder_files(host, tmp_path):
                                selected_n=4, selected_k=2, max_moves=12, warmup_batches=0, seed=11)
     finally:
         host.set_recorder("")
-    files = sorted(os.listdir(tmp_path))
+    files = sorted(os.listdir(tmp_path / "sgf"))
     sgfs = [f for f in files if f.endswith(".sgf")]
     assert sgfs and all(re.fullmatch(r"gen007_b\d{3}_g\d{3}_w3\.sgf", f) for f in sgfs)
     total = 0
     for f in sgfs:
         assert f[:-4] + ".done" in files
-        lines = open(os.path.join(tmp_path, f)).read().split("\n")
+        lines = open(tmp_path / "sgf" / f).read().split("\n")
         assert lines[-1] == ""
         n_games = int(re.search(r"_g(\d{3})_", f).group(1))
         assert len(lines) - 1 == n_games
         for ln in lines[:-1]:
-            assert ln.startswith("(;FF[4]GM[1]KM[7.5]RE[") and "PB[p3achygo]PW[p3achygo]" in ln and ln.endswith(")")
+            # komi = round(7 + clamp(N(0,1), -3, 3)) +- 0.5 (self_play_thread.cc:204-206)
+            m = re.match(r"\(;FF\[4\]GM\[1\]KM\[(-?\d+\.5)\]RE\[", ln)
+            assert m and 3.5 <= float(m.group(1)) <= 10.5
+            assert "PB[p3achygo]PW[p3achygo]" in ln and ln.endswith(")")
         total += n_games
-    assert total >= st.games
+    assert 0 < total <= st.games + 16
+    chunks = sorted(os.listdir(tmp_path / "chunks"))
+    zz = [f for f in chunks if f.endswith(".tfrecord.zz")]
+    assert zz and all(re.fullmatch(r"gen007_b\d{3}_g\d{3}_n\d{5}_t\d+_w3\.tfrecord\.zz", f) for f in zz)
+    for f in zz:
+        stem = f[:-len(".tfrecord.zz")]
+        assert {stem + ".done", stem + ".stats", stem + ".visit_count"} <= set(chunks)
+    n_examples = sum(int(re.search(r"_n(\d{5})_", f).group(1)) for f in zz)
+    assert n_examples == host.last_run_counters()[1] > 0
+
+
+def test_init_states_forks_and_reuse_buffer(host):
+    """Default policy (selfplay/main.cc:48-50,191-193): fork managers feed the GoExploit buffer
+    and new games draw from it; with init-state sampling off nothing is added."""
+    st = host.selfplay_run(None, num_games=64, num_threads=4, seconds=2.5, default_n=4, default_k=2,
+                           selected_n=4, selected_k=2, max_moves=40, warmup_batches=0, seed=5)
+    added, _ = host.last_run_counters()
+    assert st.games > 64 and added > 0
+    host.set_policy(init_state_sampling=False)
+    try:
+        host.selfplay_run(None, num_games=16, num_threads=2, seconds=0.5, default_n=4, default_k=2,
+                          selected_n=4, selected_k=2, max_moves=12, warmup_batches=0, seed=5)
+        assert host.last_run_counters()[0] == 0
+    finally:
+        host.set_policy()
+
+
+def _cround(x):
+    """std::round: halves away from zero"""
+    import math
+    return math.copysign(math.floor(abs(x) + 0.5), x)
+
+
+def _fork(host, kind, n_moves, seed, p_win=0.5, score=0):
+    import ctypes as C
+    L = host.lib()
+    L.p3host_test_fork.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+    out = np.zeros(8, np.int32)
+    komi = np.zeros(1, np.float32)
+    last5 = np.zeros(5, np.int32)
+    board = np.zeros(361, np.int8)
+    L.p3host_test_fork(kind, n_moves, seed, p_win, score, out.ctypes.data, komi.ctypes.data, last5.ctypes.data,
+                       board.ctypes.data)
+    return out, float(komi[0]), last5, board
+
+
+def test_fork_manager_late_and_random(host):
+    """ForkManager kLate / kSampleUniform (fork_manager.h:196-385): exactly one fork at the
+    sampled move number; the stored state is one or two plies past it, the colour to move and
+    stone count match, the alternative moves end the last-move list, and komi is the
+    score-neutral one: the scripted net says the side to move at the fork leads by 4.5, so
+    komi moves by round(+-4.5) from 7.5 (ComputeAdjKomi, :520-533)."""
+    seen_single = seen_double = False
+    for seed in range(1, 40):
+        for kind in (1, 4):
+            out, komi, last5, board = _fork(host, kind, 260, seed, score=4)
+            assert out[7] == kind and 10 <= out[6] <= 250
+            assert out[0] == 1
+            fork_mv = out[6]
+            plies = out[1] - fork_mv
+            assert plies in (1, 2)
+            mover = 1 if fork_mv % 2 == 0 else -1          # colour that was to move at the fork
+            assert out[2] == (mover if plies == 2 else -mover)
+            assert out[3] in (1, 2) and (kind != 4 or out[3] == 2)   # kSampleUniform forces a full search
+            assert out[4] <= fork_mv + plies and out[4] >= 1
+            assert all(0 <= x <= 361 for x in last5[-plies:])
+            if kind == 1:
+                assert 5 + 1 <= out[5] <= 2 * 36 + 1        # best-of-n candidates (+ second ply) + komi eval
+            else:
+                assert out[5] == 1                           # only the komi evaluation
+            # E[score] = +4.5 for the side to move at the evaluated position
+            if plies == 1:      # P': opponent to move and 4.5 ahead => original mover 4.5 behind
+                want = 7.5 + _cround(-4.5 if mover == 1 else 4.5)
+                assert komi == want
+                seen_single = True
+            else:               # P'': komi adjusted with probability 1/2
+                want = 7.5 + _cround(4.5 if mover == 1 else -4.5)
+                assert komi in (7.5, want)
+                seen_double = True
+    assert seen_single and seen_double
+
+
+def test_fork_manager_uniform_kind(host):
+    """kUniform (fork_manager.h:183-211, 387-394): positions are sampled with probability 5 %
+    per move and exactly one of them reaches the buffer at the end of the game, unchanged
+    (first_move_behavior kSample, same colour to move, move number = number of stones here)."""
+    added = 0
+    for seed in range(1, 30):
+        out, komi, last5, board = _fork(host, 6, 120, seed)
+        assert out[0] in (0, 1) and out[5] == 0
+        if out[0]:
+            added += 1
+            assert out[3] == 0 and out[4] == out[1]
+            assert out[2] == (1 if out[1] % 2 == 0 else -1)
+            # mcts_score 3.0 for the mover: komi either kept or shifted by round(+-3)
+            assert komi in (7.5, 7.5 + 3, 7.5 - 3)
+    assert added >= 20
+
+
+def test_init_state_distribution(host):
+    """GetInitState (self_play_thread.cc:202-252): 5 % handicap games (2-4 stones, White to
+    move, komi (h-2)*14+20.5); otherwise komi = round(7 + clamp(N(0,1),-3,3)) +- 0.5."""
+    import ctypes as C
+    L = host.lib()
+    L.p3host_test_init_states.argtypes = [C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    hc = np.zeros(1, np.int32)
+    hist = np.zeros(64, np.int32)
+    hs = np.zeros(3, np.int32)
+    n = 20000
+    L.p3host_test_init_states(7, n, hc.ctypes.data, hist.ctypes.data, hs.ctypes.data)
+    assert abs(hc[0] / n - 0.05) < 0.01
+    assert hs.sum() == hc[0] and all(abs(x / hc[0] - 1 / 3) < 0.08 for x in hs)
+    komis = {k / 2: c for k, c in enumerate(hist) if c}
+    assert min(komis) >= 3.5 and max(komis) <= 10.5 and all(k % 1 == 0.5 for k in komis)
+    assert hist.sum() == n - hc[0]
+    # round(7 + z) = 7 with probability P(|z| < 0.5) = 0.383, split evenly between 6.5 and 7.5
+    assert abs((komis[6.5] + komis[7.5] - (0.383 + 0.242) * hist.sum()) / hist.sum()) < 0.02
+
+
+def test_move_sel_manager_known_answers(host):
+    """MoveSelManager::Compute (move_sel_manager.h:41-77) with the default calibration
+    constants (:131-179) and self-play's flags kNnMctsBonus | kKldPenalty."""
+    import ctypes as C
+    L = host.lib()
+    L.p3host_test_move_sel.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+
+    def sel(n_pre, std, kld, diff, q, scale=1.0):
+        out = np.zeros(6, np.float32)
+        L.p3host_test_move_sel(n_pre, std, kld, diff, q, scale, out.ctypes.data)
+        return out
+
+    o = sel(0, 0.0, 0.0, 0.0, 0.0)                       # uninitialised root: neutral
+    assert np.allclose(o[:3], 1.0) and o[3] == pytest.approx(1.0)
+    o = sel(20, 0.1, 0.03, 0.0, 0.0)                     # low pre-KLD: penalty 1 - 0.7*(0.06-0.03)/(0.06-0.0001)
+    pen = 1 - 0.7 * (0.06 - 0.03) / (0.06 - 0.0001)
+    assert o[4] == pytest.approx(pen, rel=1e-5) and o[0] == pytest.approx(pen, rel=1e-5)
+    o = sel(20, 0.1, 0.5, 0.3982, 0.0)                   # |NN-MCTS| halfway p70..p99: bonus 1.3
+    assert o[5] == pytest.approx(1.3, rel=1e-3) and o[0] == pytest.approx(1.3, rel=1e-3)
+    o = sel(20, 0.1, 0.5, 0.3982, 0.7)                   # q attenuation: (1 - (0.7-0.5)/0.4)^0.4
+    qa = (1 - 0.5) ** 0.4
+    assert o[3] == pytest.approx(qa, rel=1e-5) and o[0] == pytest.approx(1 + qa * 0.3, rel=1e-3)
+    o = sel(20, 0.1, 0.5, 0.3982, 0.95)                  # decided position: signals off
+    assert o[0] == pytest.approx(1.0)
+    o = sel(20, 0.1, 0.5, 0.3982, 0.0, scale=0.5)        # sel_mult_scale_factor halves the effect
+    assert o[0] == pytest.approx(1.15, rel=1e-3)
+    o = sel(20, 0.1, 0.00005, 5.0, 0.0)                  # floor 0.3 and bonus cap: 1 + 0.6*(5-0.1463)/(0.65-0.1463) capped 2.5
+    assert o[4] == pytest.approx(0.3) and o[1] == pytest.approx(2.5) and o[0] == pytest.approx(0.75)

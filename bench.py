@@ -58,6 +58,22 @@ def cpu_baseline(path, pos, budget_s=12.0):
             "sample": f"{n} positions of the same batch, {MODEL} fp32 direct conv, {dt:.1f}s"}
 
 
+def hbm_traffic(kernel_name, positions):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied; see
+    profiles/r01_hbm_fetch_write_pmc.txt).  PMC collection needs the profiler around the whole
+    process, so the number is a recorded measurement of this kernel at this batch size, not
+    re-measured inside the timed run; null when the profile does not match."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_k_block_hbm_traffic.json")) as f:
+            prof = json.load(f)
+    except OSError:
+        return None
+    if prof.get("kernel") != kernel_name or prof.get("positions_per_launch") != positions:
+        return None
+    return prof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,10 +160,15 @@ def main():
     if rank == 0:
         ms, flops_launch, kname = eng.time_trunk_kernel(args.batch, 10)
         achieved = flops_launch / (ms * 1e-3) / 1e12
+        prof = hbm_traffic(kname, args.batch)
         roof = {"bound": "mfma", "kernel": kname, "achieved": achieved,
                 "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": None,
+                "frac": achieved / PEAK_FP16_MFMA_TFLOPS,
+                "traffic": prof["traffic_bytes_per_launch"] if prof else None,   # HBM bytes per launch
                 "launch_ms": ms, "algorithmic_flops_per_launch": flops_launch}
+        if prof:
+            roof["algorithmic_bytes_per_launch"] = prof["algorithmic_bytes_per_launch"]
+            roof["traffic_source"] = prof["source"]
         if n_gpus == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(path, pos)
     if world > 1:

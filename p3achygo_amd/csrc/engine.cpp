@@ -123,8 +123,19 @@ void pack_segment(std::vector<_Float16>& dst, const float* W, int taps, int ntap
 
 struct FoldedBN { size_t scale_off, shift_off; };
 
+// One conv launch of a layer-wise block (kind 4).  Buffers: 0 = x (C), 1 = t, 2 = u.
+struct LayerPlan {
+  int kw, cin, cout;
+  int pre_bn, act_bn;   // index into BlockPlan::bn, or -1
+  int res;              // residual accumulate into the output buffer
+  int in_buf, out_buf;
+  size_t stream_off = 0;
+  int nms = 0;
+};
+
 struct BlockPlan {
-  int kind;  // 0 btl, 1 nbt, 3 broadcast
+  int kind;  // 0 btl, 1 nbt, 3 broadcast, 4 layer-wise (btl/nbt at widths the fused kernel lacks)
+  std::vector<LayerPlan> layers;
   size_t stream_off = 0;
   int nms = 0;
   FoldedBN bn[p3::kMaxBlockLayers];
@@ -204,12 +215,16 @@ size_t add_stream(Arena& ar, const std::vector<_Float16>& s, int& nms, int cout_
 bool build_plan(p3hip_engine* e, Arena& ar) {
   const WeightFile& wf = e->wf;
   const int C = wf.C, Cb = wf.Cb;
-  if (!((C == 256 && Cb == 128) || (C == 128 && Cb == 64)) || wf.H != 32 || wf.V > 128 ||
+  const bool fused = (C == 256 && Cb == 128) || (C == 128 && Cb == 64);
+  const bool layerwise = (C == 384 && Cb == 192);
+  if (!(fused || layerwise) || wf.H != 32 || (wf.V != 32 && wf.V != 48 && wf.V != 64 && wf.V != 80) ||
       wf.btype > 1 || (wf.btype == 0 && (wf.inner < 1 || wf.inner > 3))) {
-    e->err = "unsupported architecture for the HIP engine (need C in {128,256}, Cb=C/2, H=32, btl/nbt)";
+    e->err = "unsupported architecture for the HIP engine (need (C, Cb) in {(128,64), (256,128), (384,192)}, "
+             "H=32, V in {32,48,64,80}, btl with 1-3 inner layers or nbt)";
     return false;
   }
-  const int CB = Cb;
+  // slice width of the per-position kernels that stage C channels (k_conv1x1 family)
+  const int CB = layerwise ? 128 : Cb;
   // init conv
   {
     std::vector<_Float16> s;
@@ -249,6 +264,34 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
       bp.stream2_off = add_stream(ar, s1, bp.nms2, 128);
       bp.stream3_off = add_stream(ar, s2, bp.nms3, CPb);
       bp.dense_bias_off = ar.add(wf.get(p + ".dense.b").data, kNLoc * 4);
+    } else if (layerwise) {
+      bp.kind = 4;
+      const int nconv = (wf.btype == 0) ? wf.inner + 2 : 6;
+      for (int j = 0; j < nconv; ++j) bp.bn[j] = fold_bn(ar, wf, p + ".bn" + std::to_string(j));
+      auto add_layer = [&](int j, int kw, int cin, int cout, int pre_bn, int act_bn, int res, int in_buf, int out_buf) {
+        LayerPlan lp{kw, cin, cout, pre_bn, act_bn, res, in_buf, out_buf};
+        std::vector<_Float16> s;
+        for (int cp = 0; cp < cout / 64; ++cp)
+          for (int ip = 0; ip < cin / 64; ++ip) pack_segment(s, W(j), kw * kw, kw * kw, cin, cout, ip * 64, 64, cp * 64, 64);
+        lp.stream_off = add_stream(ar, s, lp.nms, 64);
+        bp.layers.push_back(lp);
+      };
+      if (wf.btype == 0) {   // btl: every inner input is produced already activated
+        add_layer(0, 1, C, Cb, 0, 1, 0, 0, 1);
+        int cur = 1;
+        for (int j = 1; j <= wf.inner; ++j) {
+          add_layer(j, 3, Cb, Cb, -1, j + 1, 0, cur, 3 - cur);
+          cur = 3 - cur;
+        }
+        add_layer(wf.inner + 1, 1, Cb, C, -1, -1, 1, cur, 0);
+      } else {               // nbt: the inner residual stream t stays raw in buffer 1
+        add_layer(0, 1, C, Cb, 0, -1, 0, 0, 1);
+        add_layer(1, 3, Cb, Cb, 1, 2, 0, 1, 2);
+        add_layer(2, 3, Cb, Cb, -1, -1, 1, 2, 1);
+        add_layer(3, 3, Cb, Cb, 3, 4, 0, 1, 2);
+        add_layer(4, 3, Cb, Cb, -1, -1, 1, 2, 1);
+        add_layer(5, 1, Cb, C, 5, -1, 1, 1, 0);
+      }
     } else {
       bp.kind = wf.btype;
       const int nconv = (wf.btype == 0) ? wf.inner + 2 : 6;
@@ -317,7 +360,7 @@ p3::BlockArgs block_args(p3hip_engine* e, const BlockPlan& bp, int npos) {
 bool enqueue_forward(p3hip_engine* e, int npos) {
   const WeightFile& wf = e->wf;
   const int C = wf.C;
-  const int npw = (C == 256) ? 1 : 2;
+  const int npw = (C >= 256) ? 1 : 2;
   hipStream_t s = e->stream;
   {
     p3::InitArgs a{};
@@ -343,6 +386,17 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
       c1.in = e->d_u; c1.out16 = e->d_x; c1.npos = npos;
       c1.wstream = e->d_arena + bp.stream3_off; c1.nms_total = bp.nms3;
       if (!e->check(p3::launch_conv1x1(C, 1, c1, grid_for(e, npos, npw), s), "launch conv_last")) return false;
+    } else if (bp.kind == 4) {
+      _Float16* bufs[3] = {e->d_x, e->d_t, e->d_u};
+      for (const LayerPlan& lp : bp.layers) {
+        p3::LConvArgs a{};
+        a.in = bufs[lp.in_buf]; a.out = bufs[lp.out_buf]; a.npos = npos;
+        a.wstream = e->d_arena + lp.stream_off; a.nms_total = lp.nms;
+        a.pre = lp.pre_bn >= 0; a.act = lp.act_bn >= 0; a.res = lp.res;
+        if (a.pre) { a.scale_in = e->dev<float>(bp.bn[lp.pre_bn].scale_off); a.shift_in = e->dev<float>(bp.bn[lp.pre_bn].shift_off); }
+        if (a.act) { a.scale_out = e->dev<float>(bp.bn[lp.act_bn].scale_off); a.shift_out = e->dev<float>(bp.bn[lp.act_bn].shift_off); }
+        if (!e->check(p3::launch_lconv(lp.kw, lp.cin, lp.cout, a, grid_for(e, npos, 2), s), "launch k_lconv")) return false;
+      }
     } else {
       p3::BlockArgs a = block_args(e, bp, npos);
       if (!e->check(p3::launch_block(C, bp.kind, wf.inner, a, grid_for(e, npos, npw), s), "launch k_block")) return false;
@@ -584,7 +638,7 @@ double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
   const WeightFile& wf = e->wf;
   const BlockPlan* bp = nullptr;
   for (const BlockPlan& b : e->blocks)
-    if (b.kind != 3) { bp = &b; break; }
+    if (b.kind == 0 || b.kind == 1) { bp = &b; break; }   // fused block kernel only
   if (!bp || n_positions < 1 || n_positions > e->batch || iters < 1) return -1.0;
   const int C = wf.C, npw = (C == 256) ? 1 : 2;
   p3::BlockArgs a = block_args(e, *bp, n_positions);

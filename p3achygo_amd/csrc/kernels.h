@@ -56,6 +56,19 @@ struct Conv1x1Args {
   const float* shift;
 };
 
+// One conv layer of the layer-wise path (k_lconv): y = conv(in') [+ y], in' = mish(bn_in(in))
+// when pre != 0, y' = mish(bn_out(y)) stored instead of y when act != 0.
+struct LConvArgs {
+  const _Float16* in;   // [npos][CIN/8][361][8]
+  _Float16* out;        // [npos][COUT/8][361][8]; read as the residual when res != 0
+  int npos;
+  const void* wstream;
+  int nms_total;
+  int pre, act, res;
+  const float *scale_in, *shift_in;    // folded BN of the prologue   [CIN]
+  const float *scale_out, *shift_out;  // folded BN of the epilogue   [COUT]
+};
+
 struct BDenseArgs {
   const _Float16* t;
   _Float16* u;
@@ -94,6 +107,8 @@ hipError_t launch_init(int C, const InitArgs& a, int grid, hipStream_t s);
 // conv_last (+residual), 2 = head convs (fp32 out, COUT = 96)
 hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipStream_t s);
 hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s);
+// layer-wise conv: (kw, cin, cout) in {(1,384,192), (3,192,192), (1,192,384)}; two positions per workgroup
+hipError_t launch_lconv(int kw, int cin, int cout, const LConvArgs& a, int grid, hipStream_t s);
 hipError_t launch_heads(const HeadsArgs& a, int grid, hipStream_t s);
 const char* block_kernel_name(int C, int kind, int L);
 

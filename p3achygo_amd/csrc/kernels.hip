@@ -315,6 +315,58 @@ __global__ void __launch_bounds__(kWG, 2) k_conv1x1(Conv1x1Args a) {
 }
 
 // =======================================================================================
+// Layer-wise conv kernel for trunks whose bottleneck does not fit the fused block kernel's
+// LDS plan (C = 384, C_b = 192: one position of 192 channels on the padded grid is 168 KB).
+// Each conv of a block is its own launch; activations round-trip HBM in fp16.  A workgroup
+// owns two positions, input channels are staged in 64-channel slices (K split, accumulators
+// stay in registers across slices), outputs are produced in 64-channel passes.
+//   pre : stage mish(bn_in(.))          (ConvPreActivation prologue, model.py:203-292)
+//   act : store mish(bn_out(acc))       (the NEXT layer's prologue applied by the producer,
+//                                        so inner layers stage without VALU work)
+//   res : out += acc                    (residual, in place)
+// =======================================================================================
+template <int KW, int CIN, int COUT>
+__global__ void __launch_bounds__(kWG, 2) k_lconv(LConvArgs a) {
+  constexpr int CB = 64, NPOS = 2, CP = 64;
+  using G = Geo<NPOS, CB, KW>;
+  using T = Tiling<G, CP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  act_zero<G>(smem);
+  Ring<T::RS> ring;
+  ring_init(ring, smem, a.wstream, a.nms_total, G::ACT_BYTES);
+  lds_barrier();
+  for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS) {
+#pragma unroll 1
+    for (int cp = 0; cp < COUT / CP; ++cp) {
+      f32x16 acc[2][T::NT];
+      acc_zero<G, CP>(acc);
+#pragma unroll 1
+      for (int ip = 0; ip < CIN / CB; ++ip) {
+        lds_barrier();
+        if (a.pre) stage_in<G, true>(smem, a.in, CIN, pos0, a.npos, ip * G::NCH, a.scale_in, a.shift_in);
+        else stage_in<G, false>(smem, a.in, CIN, pos0, a.npos, ip * G::NCH, nullptr, nullptr);
+        conv_segment<G, CP, KW, KW * KW>(ring, smem, acc);
+      }
+      if (a.act) {
+        EpiParams ep;
+        epi_params<G, CP>(ep, a.scale_out, a.shift_out, cp * CP);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+          for (int j = 0; j < T::NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              acc[k >> 2][j][(k & 3) * 4 + i] = mish_f(acc[k >> 2][j][(k & 3) * 4 + i] * ep.sc[k][i] + ep.sh[k][i]);
+      }
+      if (a.res) epilogue_to_global<G, CP, true>(acc, a.out, COUT, pos0, a.npos, cp * CP);
+      else epilogue_to_global<G, CP, false>(acc, a.out, COUT, pos0, a.npos, cp * CP);
+    }
+  }
+  lds_barrier();
+  ring_drain();
+}
+
+// =======================================================================================
 // Broadcast dense: per channel c, u[c][j] = sum_i t[c][i] W[i][j] + b[j]  (Dense(361) over
 // the flattened board, weights shared by all channels; BroadcastPreAct.call, model.py:
 // 556-567; `t` already carries the mish).  Then the following ConvPreActivation prologue
@@ -730,7 +782,9 @@ static hipError_t set_lds(K kernel, size_t lds) {
 hipError_t launch_init(int C, const InitArgs& a, int grid, hipStream_t s) {
   using G = Geo<1, 16, 5>;
   constexpr size_t lds = G::ACT_BYTES + ring_bytes(128);
-  if (C == 256) {
+  if (C == 384) {
+    hipLaunchKernelGGL((k_init<384>), dim3(grid), dim3(kWG), lds, s, a);
+  } else if (C == 256) {
     hipLaunchKernelGGL((k_init<256>), dim3(grid), dim3(kWG), lds, s, a);
   } else if (C == 128) {
     hipLaunchKernelGGL((k_init<128>), dim3(grid), dim3(kWG), lds, s, a);
@@ -757,7 +811,11 @@ static hipError_t launch_conv1x1_t(const Conv1x1Args& a, int grid, hipStream_t s
 }
 
 hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipStream_t s) {
-  if (C == 256) {
+  if (C == 384) {
+    if (which == 0) return launch_conv1x1_t<384, 384, true, 0>(a, grid, s);
+    if (which == 1) return launch_conv1x1_t<384, 384, false, 1>(a, grid, s);
+    if (which == 2) return launch_conv1x1_t<384, 96, false, 2>(a, grid, s);
+  } else if (C == 256) {
     if (which == 0) return launch_conv1x1_t<256, 256, true, 0>(a, grid, s);
     if (which == 1) return launch_conv1x1_t<256, 256, false, 1>(a, grid, s);
     if (which == 2) return launch_conv1x1_t<256, 96, false, 2>(a, grid, s);
@@ -769,16 +827,40 @@ hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipS
   return hipErrorInvalidValue;
 }
 
+template <int KW, int CIN, int COUT>
+static hipError_t launch_lconv_t(const LConvArgs& a, int grid, hipStream_t s) {
+  using G = Geo<2, 64, KW>;
+  constexpr size_t lds = G::ACT_BYTES + ring_bytes(64);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = set_lds(k_lconv<KW, CIN, COUT>, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_lconv<KW, CIN, COUT>), dim3(grid), dim3(kWG), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_lconv(int kw, int cin, int cout, const LConvArgs& a, int grid, hipStream_t s) {
+  if (kw == 1 && cin == 384 && cout == 192) return launch_lconv_t<1, 384, 192>(a, grid, s);
+  if (kw == 3 && cin == 192 && cout == 192) return launch_lconv_t<3, 192, 192>(a, grid, s);
+  if (kw == 1 && cin == 192 && cout == 384) return launch_lconv_t<1, 192, 384>(a, grid, s);
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s) {
   constexpr size_t lds = 128 * kTtStride + ring_bytes(128);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = set_lds(k_bdense<256>, lds);
     if (e == hipSuccess) e = set_lds(k_bdense<128>, lds);
+    if (e == hipSuccess) e = set_lds(k_bdense<384>, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  if (C == 256) {
+  if (C == 384) {
+    hipLaunchKernelGGL((k_bdense<384>), dim3(grid), dim3(kWG), lds, s, a);
+  } else if (C == 256) {
     hipLaunchKernelGGL((k_bdense<256>), dim3(grid), dim3(kWG), lds, s, a);
   } else if (C == 128) {
     hipLaunchKernelGGL((k_bdense<128>), dim3(grid), dim3(kWG), lds, s, a);

@@ -10,7 +10,8 @@ import pytest
 
 from conftest import ROOT, load_golden
 
-SMALL = ["tiny", "test_b3c128btl2", "test_b3c128nbt", "test_b3c256btl1", "test_b3c256nbt"]
+SMALL = ["tiny", "test_b3c128btl2", "test_b3c128nbt", "test_b3c256btl1", "test_b3c256nbt", "test_b3c384btl3",
+         "test_b3c384nbt"]
 
 
 def test_model_configs_match_reference_table():

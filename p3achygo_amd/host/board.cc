@@ -1,6 +1,8 @@
 // board.cc — see board.h.  Each routine names the reference lines whose behaviour it keeps.
 #include "board.h"
 
+#include <atomic>
+
 #include <algorithm>
 
 #include "rng.h"
@@ -528,6 +530,11 @@ Grid Board::GetStonesWithLiberties(int liberties) const {
 // through full PlayMove legality (suicide, superko, pass-alive prohibition).  All choices are
 // any/all quantifiers over the candidate moves, so the verdict does not depend on visiting
 // order and this restatement is free to enumerate liberties its own way.
+constexpr long kLadderNodeBudget = 20000;
+thread_local long t_ladder_nodes = 0;
+thread_local bool t_ladder_exhausted = false;
+std::atomic<long> g_ladder_calls{0}, g_ladder_nodes{0}, g_ladder_max{0}, g_ladder_exhausted{0};
+
 struct LadderSolver {
   static int FindLiberties(const Board& b, int head, int out[2]) {
     g_marks2.next();
@@ -568,6 +575,11 @@ struct LadderSolver {
   // moved (the opponent of color_to_move) and reads on.
   static bool Solve(Board& board, Color g_color, Color color_to_move, int root, int last_move, int depth) {
     if (depth > 300) return false;
+    // Work bound (not in the reference, whose only bound is the depth): the read-out is
+    // exponential on chaotic positions with many groups in atari (seconds per call), and one
+    // stalled game stalls the whole evaluation batch.  An exhausted budget reads as "not
+    // laddered", like the depth bound; real ladders resolve in well under 1 % of it.
+    if (++t_ladder_nodes > kLadderNodeBudget) { t_ladder_exhausted = true; return false; }
     if (!MoveOk(board.PlayMove(AsLoc(last_move), Opp(color_to_move)))) return g_color != color_to_move;
     const int gid = board.gid_[root];
     if (gid < 0) return true;  // captured (not reachable through the reads below)
@@ -608,9 +620,17 @@ Grid Board::GetLadderedStones() const {
     if (EmptyNeighbors(l[0]) >= 3) continue;  // IsLaddered pre-check, board.cc:857-861
     const Color g_color = stones_[p];
     Board copy = *this;
+    t_ladder_nodes = 0;
+    t_ladder_exhausted = false;
     // the reference anchors the group by its root stone; any stone of it works since the
     // group can only grow while it is being read
-    if (LadderSolver::Solve(copy, g_color, Opp(g_color), p, l[0], 0)) {
+    const bool laddered = LadderSolver::Solve(copy, g_color, Opp(g_color), p, l[0], 0);
+    g_ladder_calls.fetch_add(1, std::memory_order_relaxed);
+    g_ladder_nodes.fetch_add(t_ladder_nodes, std::memory_order_relaxed);
+    if (t_ladder_exhausted) g_ladder_exhausted.fetch_add(1, std::memory_order_relaxed);
+    for (long m = g_ladder_max.load(std::memory_order_relaxed); t_ladder_nodes > m &&
+         !g_ladder_max.compare_exchange_weak(m, t_ladder_nodes, std::memory_order_relaxed);) {}
+    if (laddered) {
       int s = p;
       do {
         data[s] = g_color;
@@ -619,6 +639,10 @@ Grid Board::GetLadderedStones() const {
     }
   }
   return data;
+}
+
+void LadderStats(long out[4]) {
+  out[0] = g_ladder_calls.load(); out[1] = g_ladder_nodes.load(); out[2] = g_ladder_max.load(); out[3] = g_ladder_exhausted.load();
 }
 
 // ---------------------------------------------------------------------------------------

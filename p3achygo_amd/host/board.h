@@ -142,6 +142,9 @@ class Board {
   std::shared_ptr<const SeenTable> base_;  // older keys, shared between copies (may be null)
 };
 
+// ladder read-out statistics since process start: calls, nodes, max nodes of one call, budget hits
+void LadderStats(long out[4]);
+
 // cc/game/game.{h,cc}: a board plus the move list (five leading noop moves) and result.
 struct Move {
   Color color;

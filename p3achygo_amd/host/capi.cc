@@ -180,6 +180,7 @@ int p3host_tfrec_record(void* r, const int* moves, int n, float komi, const floa
   return 0;
 }
 uint32_t p3host_crc32c(const void* p, size_t n) { return Crc32c(p, n); }
+void p3host_ladder_stats(long* out) { LadderStats(out); }
 }
 
 // ---- fork manager / init-state / move-selection tests ----------------------------------------
@@ -276,5 +277,61 @@ void p3host_test_move_sel(int n_pre, float std_dev, float pre_kld, float nn_mcts
   MoveSelResult r = m.Compute(n_pre, std_dev, pre_kld, nn_mcts_diff, q, scale);
   out[0] = r.modifier; out[1] = r.sel_bonus; out[2] = r.sel_penalty; out[3] = r.sel_q_adjust;
   out[4] = r.sel_kld_penalty; out[5] = r.sel_nn_mcts_bonus;
+}
+}
+
+// ---- parallel (batch) search tests: cc/mcts/__tests__/search_test.cc:130-222 -------------------
+#include "parallel_search.h"
+
+extern "C" {
+float p3host_t_quantile(int dof) { return CachedTQuantile(dof); }
+
+// NullEngine of the reference test (uniform policy, value 0.5/0.5, uniform score bins) and its
+// MakeEvaluatedRoot; runs one BatchSearch from the empty board.
+// out: [0] visits [1] aborted [2] collisions [3] rounds [4] root n [5] move index (-1 noop)
+//      [6] sum of root child visits [7] nodes whose n != 1 + sum(child visits) (must be 0)
+//      [8] nodes left with n_in_flight != 0 (must be 0) [9] evaluations requested
+int p3host_test_batch_search(int batch, int budget, int* out) {
+  Game game(7.5f, true);
+  NodePool pool;
+  TreeNode* root = pool.Create();
+  root->evaluated = true;
+  root->color_to_move = kBlack;
+  root->n = 1;
+  for (int a = 0; a < kNumMoves; ++a) { root->move_probs[a] = 1.0f / kNumMoves; root->move_logits[a] = 0; root->opt_probs[a] = 1.0f / kNumMoves; }
+  p3hip_result r;
+  std::memset(&r, 0, sizeof r);
+  for (int a = 0; a < kNumMoves; ++a) { r.move_probs[a] = 1.0f / kNumMoves; r.opt_move_probs[a] = 1.0f / kNumMoves; }
+  r.value_probs[0] = r.value_probs[1] = 0.5f;
+  for (int i = 0; i < P3HIP_NUM_SCORE_LOGITS; ++i) r.score_probs[i] = 1.0f / P3HIP_NUM_SCORE_LOGITS;
+  ParallelSearchParams p;
+  p.batch = batch;
+  p.visit_budget = budget;
+  BatchSearch s;
+  s.Begin(&game, &pool, root, kBlack, p);
+  int evals = 0;
+  for (int n; (n = s.Step()) > 0;) {
+    for (int i = 0; i < n; ++i) s.Deliver(i, r);
+    evals += n;
+  }
+  const ParallelSearchResult& res = s.result();
+  out[0] = res.num_visits; out[1] = res.num_aborted; out[2] = res.num_collisions; out[3] = res.rounds;
+  out[4] = root->n;
+  out[5] = res.move == kNoopLoc ? -1 : MoveIdx(res.move);
+  int sum = 0;
+  for (const ChildEdge& e : root->children) sum += e.visits;
+  out[6] = sum;
+  int bad_n = 0, bad_if = 0;
+  std::vector<TreeNode*> stack{root};
+  while (!stack.empty()) {
+    TreeNode* nd = stack.back();
+    stack.pop_back();
+    int cs = 0;
+    for (const ChildEdge& e : nd->children) { cs += e.visits; if (e.node) stack.push_back(e.node); }
+    if (nd->n != 1 + cs && !(nd->is_terminal && cs == 0)) ++bad_n;
+    if (nd->n_in_flight != 0) ++bad_if;
+  }
+  out[7] = bad_n; out[8] = bad_if; out[9] = evals;
+  return 0;
 }
 }

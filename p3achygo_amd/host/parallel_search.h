@@ -1,0 +1,412 @@
+// parallel_search.h — the multi-leaf PUCT search used by the evaluation path.
+//
+// Restates mcts::Search (cc/mcts/search.{h,cc}) in its batch form, BatchSearch
+// (search.cc:487-640): every round makes `batch` descents from the root — the first follows
+// the best PUCT action everywhere, each later one forks an earlier path of the round at the
+// node whose runner-up action has the smallest PUCT gap — collects the new leaves, has them
+// evaluated TOGETHER, and backs the round up deepest-node-first (TopologicalBackup,
+// search.cc:247-270) with RecomputeNodeStats (tree.h:175-241).  The final move is the legal
+// move with the best lower confidence bound (Search::Run, search.cc:742-760,833).
+//
+// The reference's concurrent mode runs the same round structure on `num_threads` OS threads
+// per game with per-node mutexes and two barriers per round; its batch mode is the
+// single-threaded statement of it and is the one that maps onto this host, where a search
+// never blocks: Step() returns the leaves of a round, the scheduler evaluates them in the
+// engine's next batch together with every other game's, Deliver()/Step() continue.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <unordered_set>
+#include <vector>
+
+#include "board.h"
+#include "search.h"
+
+namespace p3 {
+
+
+// ---- Student-t quantiles for the confidence bounds (tree.cc:14-40: boost students_t) ---------
+inline double BetaCf(double a, double b, double x) {   // continued fraction of I_x(a, b)
+  const double tiny = 1e-300;
+  double qab = a + b, qap = a + 1, qam = a - 1, c = 1, d = 1 - qab * x / qap;
+  if (std::abs(d) < tiny) d = tiny;
+  d = 1 / d;
+  double h = d;
+  for (int m = 1; m <= 500; ++m) {
+    const int m2 = 2 * m;
+    double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+    d = 1 + aa * d; if (std::abs(d) < tiny) d = tiny;
+    c = 1 + aa / c; if (std::abs(c) < tiny) c = tiny;
+    d = 1 / d; h *= d * c;
+    aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+    d = 1 + aa * d; if (std::abs(d) < tiny) d = tiny;
+    c = 1 + aa / c; if (std::abs(c) < tiny) c = tiny;
+    d = 1 / d;
+    const double del = d * c;
+    h *= del;
+    if (std::abs(del - 1) < 1e-15) break;
+  }
+  return h;
+}
+inline double RegIncBeta(double a, double b, double x) {
+  if (x <= 0) return 0;
+  if (x >= 1) return 1;
+  const double bt = std::exp(std::lgamma(a + b) - std::lgamma(a) - std::lgamma(b) + a * std::log(x) + b * std::log(1 - x));
+  return x < (a + 1) / (a + b + 2) ? bt * BetaCf(a, b, x) / a : 1 - bt * BetaCf(b, a, 1 - x) / b;
+}
+// upper-tail quantile: t with P(T_nu > t) = p  (0 < p < 0.5)
+inline double StudentTUpperQuantile(double nu, double p) {
+  auto upper = [&](double t) { return 0.5 * RegIncBeta(nu / 2, 0.5, nu / (nu + t * t)); };
+  double lo = 0, hi = 1;
+  while (upper(hi) > p) hi *= 2;
+  for (int i = 0; i < 200; ++i) {
+    const double mid = 0.5 * (lo + hi);
+    (upper(mid) > p ? lo : hi) = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+constexpr float kLcbAlpha = 0.05f;   // tree.cc:15
+inline float CachedTQuantile(int v) {   // tree.cc:16-33: two-sided alpha = 0.05, dof 1..1000
+  static const std::array<float, 1000> table = [] {
+    std::array<float, 1000> t;
+    for (int i = 1; i <= 1000; ++i) t[i - 1] = (float)StudentTUpperQuantile(i, kLcbAlpha / 2);
+    return t;
+  }();
+  if (v < 1) return table[0];
+  if (v < 1000) return table[v - 1];
+  return table.back();
+}
+inline float VVar(const TreeNode* n) { return !n || n->n < 3 ? kMaxQ : n->v_var; }   // tree.h:110-112
+inline std::pair<float, float> ConfidenceInterval(const TreeNode* node, int a) {   // tree.cc:42-55
+  const float n = (float)node->child_visits(a);
+  const TreeNode* ch = node->child(a);
+  if (!ch || n < 2) return {-1e6f + n, 1e6f - n};
+  const float stddev = std::sqrt(VVar(ch) / n);
+  const float z = CachedTQuantile((int)n - 1);
+  return {Q(node, a) - z * stddev, Q(node, a) + z * stddev};
+}
+inline float Lcb(const TreeNode* node, int a) { return ConfidenceInterval(node, a).first; }
+inline float Ucb(const TreeNode* node, int a) { return ConfidenceInterval(node, a).second; }
+
+// ---- PUCT scores, top-4 (search_policy.h:159-351, IdentityQ / IdentityN) ---------------------
+inline void PuctScoresAll(const TreeNode* node, const PuctParams& pp, bool is_root, float* scores) {
+  const int n = node->n;
+  const float v = node->v;
+  int cv[kNumMoves] = {};
+  float qs[kNumMoves], qvars[kNumMoves];
+  float q_std_weighted = 0;
+  for (const ChildEdge& e : node->children) {
+    cv[e.action] = e.visits;
+    if (e.visits > 0) qs[e.action] = -e.node->v;
+    if (e.visits >= 3) {
+      qvars[e.action] = e.node->v_var;
+      q_std_weighted += std::sqrt(qvars[e.action]) * e.visits;
+    }
+  }
+  const float q_std_mean = q_std_weighted / n;
+  float p_explored = 0;
+  for (const ChildEdge& e : node->children)
+    if (e.visits > 0) p_explored += node->move_probs[e.action];
+  const float v_fpu = v - (is_root ? pp.root_fpu : kDefaultFPU) * std::sqrt(p_explored);
+  const float c_puct = pp.c_puct + pp.c_puct_visit_scaling * std::log((n + 500.0f) / 500.0f);
+  float total_n = 1;
+  for (const ChildEdge& e : node->children) total_n += e.visits;
+  const float sqrt_n = std::sqrt(total_n);
+  for (int a = 0; a < kNumMoves; ++a) {
+    float scale = 1.0f;
+    if (pp.enable_var_scaling && cv[a] >= 3 && q_std_mean != 0) {
+      const float pw = (float)pp.var_scale_prior_visits;
+      scale = (pw + cv[a] * (std::sqrt(qvars[a]) / q_std_mean)) / (pw + cv[a]);
+    }
+    scores[a] = c_puct * scale * node->move_probs[a] * (sqrt_n / (1 + cv[a])) + (cv[a] > 0 ? qs[a] : v_fpu);
+  }
+}
+
+using TopActions = std::array<std::pair<int, float>, 4>;   // (action or -1, score)
+inline TopActions PuctTopScores(const TreeNode* node, const Board& board, Color color, const PuctParams& pp,
+                                bool is_root) {   // search_policy.h:318-351
+  float scores[kNumMoves];
+  PuctScoresAll(node, pp, is_root, scores);
+  TopActions top;
+  top.fill({-1, -1e6f});
+  for (int a = 0; a < kNumMoves; ++a) {
+    int rank = 0;
+    while (rank < 4 && !(scores[a] > top[rank].second)) ++rank;
+    if (rank >= 4 || !board.IsValidMove(MoveLoc(a), color)) continue;
+    for (int r = 3; r > rank; --r) top[r] = top[r - 1];
+    top[rank] = {a, scores[a]};
+  }
+  return top;
+}
+
+// tree.h:175-241 (no bias cache: obs_bias = 0)
+inline void RecomputeNodeStats(TreeNode* node) {
+  float w = node->init_util_est, w_outcome = node->init_outcome_est, total_score = node->init_score_est,
+        w_err = node->init_err_est;
+  int max_child_n = 0;
+  for (const ChildEdge& e : node->children) {
+    if (!e.node) continue;
+    w -= e.visits * e.node->v;
+    w_outcome -= e.visits * e.node->v_outcome;
+    total_score -= e.visits * e.node->score;
+    max_child_n = std::max(max_child_n, e.visits);
+    w_err += e.visits * e.node->v_err;
+  }
+  const float v = w / node->n, v_outcome = w_outcome / node->n;
+  const float m = node->init_util_est - v, m_outcome = node->init_outcome_est - v_outcome;
+  float m2 = m * m, m2_outcome = m_outcome * m_outcome;
+  double m3 = m2 * m, m3_outcome = m2_outcome * m_outcome;
+  for (const ChildEdge& e : node->children) {
+    if (e.visits == 0 || !e.node) continue;
+    const float dv = -e.node->v - v, dvo = -e.node->v_outcome - v_outcome;
+    m2 += e.visits * (e.node->v_var + dv * dv);
+    m2_outcome += e.visits * (e.node->v_outcome_var + dvo * dvo);
+    m3 += e.visits * (-e.node->v_m3 + 3 * e.node->v_var * dv + dv * dv * dv);
+    m3_outcome += e.visits * (-e.node->v_outcome_m3 + 3 * e.node->v_outcome_var * dvo + dvo * dvo * dvo);
+  }
+  node->w = w; node->w_outcome = w_outcome; node->v = v; node->v_outcome = v_outcome;
+  node->score = total_score / node->n;
+  node->max_child_n = max_child_n;
+  node->v_var = m2 / node->n; node->v_outcome_var = m2_outcome / node->n;
+  node->v_m3 = m3 / node->n; node->v_outcome_m3 = m3_outcome / node->n;
+  node->v_err = w_err / node->n;
+}
+
+struct ParallelSearchParams {   // Search::Params (search.h:92-107), batch mode
+  int batch = 8;                // num_threads: leaves per round
+  int visit_budget = 128;       // total_visit_budget
+  PuctParams puct;
+};
+struct ParallelSearchResult {   // Search::Result
+  Loc move = kPassLoc;
+  int num_visits = 0, num_aborted = 0, num_collisions = 0, rounds = 0;
+};
+
+class BatchSearch {
+ public:
+  // `game`, `pool` and `root` (a node of `pool` for the position of `game`) must outlive the search.
+  void Begin(const Game* game, NodePool* pool, TreeNode* root, Color color, const ParallelSearchParams& p) {
+    game_ = game; pool_ = pool; root_ = root; color_ = color; p_ = p;
+    res_ = ParallelSearchResult{};
+    root_pos_ = Position(*game);
+    if (p_.batch > kMaxBatch) p_.batch = kMaxBatch;
+    workers_.assign(p_.batch, Worker{});
+    pending_.resize(p_.batch);
+    n_evals_ = 0;
+    state_ = game->IsGameOver() ? State::kDone : (root->evaluated ? State::kRound : State::kRootEval);
+  }
+
+  // Advances until network evaluations are needed; returns how many (0: the search is done).
+  int Step() {
+    for (;;) {
+      switch (state_) {
+        case State::kDone:
+          return 0;
+        case State::kRootEval:   // search.cc:781-787
+          eval_pos_[0] = &root_pos_;
+          eval_color_[0] = color_;
+          eval_worker_[0] = -1;
+          n_evals_ = 1;
+          state_ = State::kRootEvalWait;
+          return 1;
+        case State::kRootEvalWait:
+          EvaluateRoot(pending_[0], root_, color_);
+          state_ = State::kRound;
+          break;
+        case State::kRound:
+          if (res_.num_visits >= p_.visit_budget) { Finish(); return 0; }
+          DescendRound();
+          state_ = State::kRoundWait;
+          if (n_evals_ > 0) return n_evals_;
+          break;
+        case State::kRoundWait:
+          FetchAndBackup();
+          state_ = State::kRound;
+          break;
+      }
+    }
+  }
+  const Position& eval_pos(int i) const { return *eval_pos_[i]; }
+  Color eval_color(int i) const { return eval_color_[i]; }
+  void Deliver(int i, const p3hip_result& r) { pending_[i] = r; }
+  const ParallelSearchResult& result() const { return res_; }
+
+ private:
+  enum class State { kRootEval, kRootEvalWait, kRound, kRoundWait, kDone };
+  struct PathElem { TreeNode* node; int action; TopActions top; };   // action -1 = leaf marker
+  struct Worker {
+    std::vector<PathElem> path;
+    Position pos;
+    bool aborted = false, needs_eval = false;
+    Color leaf_color = kBlack;
+    int eval_slot = -1;
+  };
+  struct Fork { float diff; int path_num, path_index, puct_index; };
+
+  // Descend (search.cc:84-245) for one worker; false on collision (the path is undone).
+  bool Descend(Worker& w, const std::vector<PathElem>& prefix) {
+    w.pos = root_pos_;
+    w.path.clear();
+    Color c = color_;
+    in_flight(root_)++;
+    TreeNode* cur = root_;
+    auto collide = [&]() {
+      for (PathElem& e : w.path) in_flight(e.node)--;
+      return false;
+    };
+    for (size_t idx = 0;; ++idx) {
+      if (!cur->evaluated) {   // a leaf claimed earlier in this round
+        w.path.push_back({cur, -1, {}});
+        return collide();
+      }
+      int action;
+      TopActions top;
+      if (idx < prefix.size()) { action = prefix[idx].action; top = prefix[idx].top; }
+      else { top = PuctTopScores(cur, w.pos.board, c, p_.puct, cur == root_); action = top[0].first; }
+      if (action < 0) action = kPassEncoding;   // no legal scored move: pass is always legal
+      w.pos.PlayMove(MoveLoc(action), c);
+      c = Opp(c);
+      w.path.push_back({cur, action, top});
+      TreeNode* child = cur->child(action);
+      int child_in_flight;
+      if (child) {
+        child_in_flight = in_flight(child)++;
+      } else {
+        child = pool_->Create();
+        child->color_to_move = c;
+        child->is_terminal = w.pos.IsGameOver();
+        child_in_flight = in_flight(child)++;
+        cur->children.push_back(ChildEdge{(int16_t)action, 0, child});
+        cur = child;   // a new node: claimed by this descent
+        break;
+      }
+      cur = child;
+      if (w.pos.IsGameOver() || child->is_terminal) {
+        if (child_in_flight == 0) break;      // this descent claims the terminal node
+        w.path.push_back({child, -1, {}});    // already claimed in this round
+        return collide();
+      }
+    }
+    w.path.push_back({cur, -1, {}});
+    if (w.pos.IsGameOver()) cur->is_terminal = true;
+    w.needs_eval = !cur->evaluated && !w.pos.IsGameOver();
+    w.leaf_color = c;
+    return true;
+  }
+
+  void DescendRound() {   // search.cc:536-597
+    forks_.clear();
+    stored_forks_.clear();
+    backup_.clear();
+    n_evals_ = 0;
+    for (int wi = 0; wi < p_.batch; ++wi) {
+      Worker& w = workers_[wi];
+      w.aborted = false;
+      w.needs_eval = false;
+      std::vector<PathElem> prefix;
+      if (!forks_.empty()) {   // fork with the smallest PUCT gap first
+        auto it = std::min_element(forks_.begin(), forks_.end(), [](const Fork& a, const Fork& b) { return a.diff < b.diff; });
+        const Fork f = *it;
+        forks_.erase(it);
+        const std::vector<PathElem>& src = workers_[f.path_num].path;
+        prefix.assign(src.begin(), src.begin() + f.path_index + 1);
+        prefix.back().action = prefix.back().top[f.puct_index].first;
+      }
+      if (!Descend(w, prefix)) {
+        w.aborted = true;
+        w.path.clear();
+        ++res_.num_aborted;
+        ++res_.num_collisions;
+        continue;
+      }
+      for (int pi = 0; pi < (int)w.path.size(); ++pi) {
+        const PathElem& e = w.path[pi];
+        backup_.push_back(BackupElem{pi, e.node, e.action, pi == (int)w.path.size() - 1});
+        if (e.action < 0) continue;   // the leaf has no scored actions
+        if (stored_forks_.count(e.node)) continue;
+        for (int k = 1; k < 4; ++k) {
+          if (e.top[k].first < 0) continue;
+          forks_.push_back(Fork{std::abs(e.top[0].second - e.top[k].second), wi, pi, k});
+        }
+        stored_forks_.insert(e.node);
+      }
+      if (w.needs_eval) {
+        w.eval_slot = n_evals_;
+        eval_pos_[n_evals_] = &w.pos;
+        eval_color_[n_evals_] = w.leaf_color;
+        eval_worker_[n_evals_] = wi;
+        ++n_evals_;
+      }
+    }
+  }
+
+  void FetchAndBackup() {   // search.cc:603-640
+    for (int wi = 0; wi < p_.batch; ++wi) {
+      Worker& w = workers_[wi];
+      if (w.aborted) continue;
+      TreeNode* leaf = w.path.back().node;
+      if (w.needs_eval) EvaluateLeaf(pending_[w.eval_slot], leaf, w.leaf_color, color_, root_->init_score_est);
+      if (w.pos.IsGameOver()) {
+        Scores s = w.pos.GetScores();
+        EvaluateTerminal(s, leaf, w.leaf_color, color_, root_->init_score_est);
+      }
+      ++res_.num_visits;
+    }
+    // deepest first; a node is finalised on the last entry that passes through it
+    std::stable_sort(backup_.begin(), backup_.end(), [](const BackupElem& a, const BackupElem& b) { return a.depth > b.depth; });
+    for (const BackupElem& b : backup_) {
+      TreeNode* node = b.node;
+      node->n += 1;
+      if (!b.is_leaf) {
+        ChildEdge* e = node->edge(b.action);
+        if (e) e->visits += 1;
+      }
+      if (--in_flight(node) == 0) {
+        if (b.is_leaf) {
+          node->w = node->v = node->init_util_est;
+          node->w_outcome = node->v_outcome = node->init_outcome_est;
+        } else {
+          RecomputeNodeStats(node);
+        }
+      }
+    }
+    ++res_.rounds;
+    n_evals_ = 0;
+  }
+
+  void Finish() {   // best_lcb_move, search.cc:742-760
+    std::array<std::pair<int, float>, kNumMoves> lcbs;
+    for (int a = 0; a < kNumMoves; ++a) lcbs[a] = {a, Lcb(root_, a)};
+    std::stable_sort(lcbs.begin(), lcbs.end(), [](const auto& x, const auto& y) { return y.second < x.second; });
+    res_.move = kPassLoc;
+    for (const auto& [a, lcb] : lcbs)
+      if (root_pos_.board.IsValidMove(MoveLoc(a), color_)) { res_.move = MoveLoc(a); break; }
+    state_ = State::kDone;
+  }
+
+  int& in_flight(TreeNode* n) { return n->n_in_flight; }
+
+  struct BackupElem { int depth; TreeNode* node; int action; bool is_leaf; };
+  static constexpr int kMaxBatch = 64;
+
+  const Game* game_ = nullptr;
+  NodePool* pool_ = nullptr;
+  TreeNode* root_ = nullptr;
+  Color color_ = kBlack;
+  ParallelSearchParams p_;
+  ParallelSearchResult res_;
+  State state_ = State::kDone;
+  Position root_pos_;
+  std::vector<Worker> workers_;
+  std::vector<Fork> forks_;
+  std::unordered_set<TreeNode*> stored_forks_;
+  std::vector<BackupElem> backup_;
+  const Position* eval_pos_[kMaxBatch];
+  Color eval_color_[kMaxBatch];
+  int eval_worker_[kMaxBatch];
+  std::vector<p3hip_result> pending_;
+  int n_evals_ = 0;
+};
+
+}  // namespace p3

@@ -59,6 +59,7 @@ struct TreeNode {                                        // cc/mcts/tree.h:21-91
   float move_logits[kNumMoves], move_probs[kNumMoves], opt_probs[kNumMoves];
   float init_outcome_est = 0, init_score_est = 0, init_score_var = 0, init_util_est = 0, init_err_est = 0;
   uint32_t mark = 0;  // NodePool::Reap
+  int n_in_flight = 0;  // descents of the current round through this node (parallel_search.h)
 
   ChildEdge* edge(int a) {
     for (auto& e : children)

@@ -846,3 +846,105 @@ int p3host_selfplay_one_game(const char* engine_lib, const char* weights, int de
 }
 
 }  // extern "C"
+
+// ---- evaluation matches (cc/eval) ------------------------------------------------------------
+#include "eval_match.h"
+
+extern "C" {
+
+struct p3host_eval_stats {
+  int games, cur_wins, cand_wins, draws, resignations;
+  long moves, visits, collisions, positions, batches;
+  double seconds;
+};
+
+// Plays `num_games` evaluation games between two networks with the batch parallel search
+// (eval.cc:103-518).  engine_lib NULL/"" = NullEvaluator for both players.  One engine
+// instance per player, batch = num_games * leaves_per_round slots.
+int p3host_eval_match(const char* engine_lib, const char* cur_weights, const char* cand_weights, int device,
+                      int num_games, int visits_per_move, int leaves_per_round, int max_moves, int num_threads,
+                      uint64_t seed, p3host_eval_stats* out, char* err) {
+  EvalPlayerConfig pc;
+  pc.n = visits_per_move;
+  pc.num_threads_per_game = leaves_per_round;
+  const int slots = num_games * leaves_per_round;
+  std::unique_ptr<Evaluator> ev[2];
+  const bool use_null = !engine_lib || !engine_lib[0];
+  for (int e = 0; e < 2; ++e) {
+    if (use_null) {
+      ev[e].reset(new NullEvaluator());
+    } else {
+      auto* h = new HipEvaluator();
+      ev[e].reset(h);
+      if (!h->Open(engine_lib, e == 0 ? cur_weights : cand_weights, slots, device)) {
+        if (err) snprintf(err, 256, "%s", h->err.c_str());
+        return 1;
+      }
+    }
+  }
+  std::vector<std::unique_ptr<EvalGame>> games;
+  for (int g = 0; g < num_games; ++g)
+    games.emplace_back(new EvalGame(g, pc, pc, max_moves, seed * 0x9E3779B97F4A7C15ull + (uint64_t)g * 0xBF58476D1CE4E5B9ull));
+  WorkerPool pool(num_threads > 0 ? num_threads : 1);
+  std::vector<int> want(num_games, 0), base(num_games, 0);
+  std::vector<p3hip_features> feats(slots);
+  long positions = 0, batches = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  // every game starts wanting evaluations from the engine of its side to move
+  pool.ParallelFor(num_games, [&](int g) { want[g] = games[g]->Step(); });
+  for (;;) {
+    bool any = false;
+    for (int e = 0; e < 2; ++e) {
+      int total = 0;
+      for (int g = 0; g < num_games; ++g) {
+        base[g] = -1;
+        if (want[g] > 0 && games[g]->active_engine() == e) { base[g] = total; total += want[g]; }
+      }
+      if (total == 0) continue;
+      any = true;
+      pool.ParallelFor(num_games, [&](int g) {
+        if (base[g] < 0) return;
+        for (int i = 0; i < want[g]; ++i) {
+          games[g]->FillEval(i, &feats[base[g] + i]);
+          ev[e]->Load(base[g] + i, feats[base[g] + i]);
+        }
+      });
+      if (!ev[e]->Run()) {
+        if (err) snprintf(err, 256, "engine run failed");
+        return 2;
+      }
+      positions += total;
+      ++batches;
+      pool.ParallelFor(num_games, [&](int g) {
+        if (base[g] < 0) return;
+        p3hip_result r;
+        for (int i = 0; i < want[g]; ++i) {
+          ev[e]->Get(base[g] + i, r);
+          games[g]->Deliver(i, r);
+        }
+        want[g] = games[g]->Step();
+      });
+    }
+    if (!any) break;
+  }
+  if (out) {
+    std::memset(out, 0, sizeof *out);
+    out->games = num_games;
+    for (auto& g : games) {
+      const int r = g->cur_result();
+      out->cur_wins += r > 0;
+      out->cand_wins += r < 0;
+      out->draws += r == 0;
+      out->resignations += g->resigned();
+      out->moves += g->num_moves();
+      out->visits += g->visits();
+      out->collisions += g->collisions();
+    }
+    out->positions = positions;
+    out->batches = batches;
+    out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return 0;
+}
+
+}  // extern "C"

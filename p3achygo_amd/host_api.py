@@ -208,3 +208,27 @@ def sgf_from_moves(moves, komi: float = 7.5, write_result: bool = False, b_name:
                                 b_name.encode(), w_name.encode(), out, len(out))
     assert n >= 0
     return out.value.decode()
+
+
+class EvalStats(C.Structure):
+    _fields_ = [("games", C.c_int), ("cur_wins", C.c_int), ("cand_wins", C.c_int), ("draws", C.c_int),
+                ("resignations", C.c_int), ("moves", C.c_long), ("visits", C.c_long), ("collisions", C.c_long),
+                ("positions", C.c_long), ("batches", C.c_long), ("seconds", C.c_double)]
+
+
+def eval_match(cur_weights: str | None, cand_weights: str | None, num_games: int, visits_per_move: int = 128,
+               leaves_per_round: int = 8, max_moves: int = 600, num_threads: int = 8, seed: int = 1,
+               device: int = 0) -> EvalStats:
+    """Model-vs-model games with the batch parallel search (cc/eval).  weights=None -> NullEvaluator."""
+    L = lib()
+    L.p3host_eval_match.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_uint64, C.POINTER(EvalStats), C.c_char_p]
+    st = EvalStats()
+    err = C.create_string_buffer(256)
+    elib = os.path.join(_HERE, "csrc", "libp3hip.so").encode() if cur_weights else None
+    rc = L.p3host_eval_match(elib, cur_weights.encode() if cur_weights else None,
+                             cand_weights.encode() if cand_weights else None, device, num_games, visits_per_move,
+                             leaves_per_round, max_moves, num_threads, seed, C.byref(st), err)
+    if rc != 0:
+        raise RuntimeError(f"eval_match rc={rc}: {err.value.decode()}")
+    return st

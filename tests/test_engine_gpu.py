@@ -159,3 +159,14 @@ def test_selfplay_host_on_hip_engine(built, weight_files):
     mv, bs, ws, ev = host_api.selfplay_one_game(weight_files("test_b3c128btl2"), 8, 4, 80, seed=9)
     mv2, *_ = host_api.selfplay_one_game(weight_files("test_b3c128btl2"), 8, 4, 80, seed=9)
     assert len(mv) > 10 and np.array_equal(mv, mv2)   # deterministic on the GPU too
+
+
+@pytest.mark.gpu
+def test_eval_match_on_hip_engines(built, weight_files):
+    """Config 5 plumbing: two different networks, each behind its own HIP
+    engine instance, play evaluation games with the batch parallel search."""
+    from p3achygo_amd import host_api
+    st = host_api.eval_match(weight_files("test_b3c384nbt"), weight_files("test_b3c256btl1"), num_games=8,
+                             visits_per_move=16, leaves_per_round=4, max_moves=24, num_threads=4, seed=2)
+    assert st.games == 8 and st.cur_wins + st.cand_wins + st.draws == 8
+    assert st.visits >= 16 * (st.moves - 8) and st.positions > 0 and st.batches > 0

@@ -140,14 +140,15 @@ def main():
         from p3achygo_amd import host_api
         cpus = len(os.sched_getaffinity(0))
         threads = max(2, min(16, cpus // max(world, 1)))
-        st = host_api.selfplay_run(path, 2 * args.batch, threads, args.selfplay_seconds, default_n=32,
+        host_api.set_groups(3)   # three game groups: two forward passes in flight while one group is on the host
+        st = host_api.selfplay_run(path, 3 * args.batch, threads, args.selfplay_seconds, default_n=32,
                                    default_k=5, selected_n=32, selected_k=5, warmup_batches=4,
                                    seed=77 + rank, device=local_rank)
         sp = torch.tensor([st.positions / st.seconds, st.moves / st.seconds], dtype=torch.float64)
         if world > 1:
             dist.all_reduce(sp, op=dist.ReduceOp.SUM)
         selfplay = {"value": float(sp[0]), "unit": "positions/s", "moves_per_s": float(sp[1]),
-                    "concurrent_games_per_gpu": 2 * args.batch, "batch": args.batch,
+                    "concurrent_games_per_gpu": 3 * args.batch, "batch": args.batch, "game_groups": 3,
                     "host_threads_per_gpu": threads, "seconds": st.seconds,
                     "gumbel": "n=32 (default k<=5, selected k=5)", "includes": "host MCTS + PCIe + engine"}
     eng = engine.create_engine(engine.kind_from_engine_path(path), path, args.batch, 1, device=local_rank)

@@ -580,6 +580,7 @@ std::string g_rec_dir, g_rec_worker = "0";
 int g_rec_gen = 0, g_rec_flush_interval = 128;   // --flush_interval, selfplay/main.cc:35
 bool g_init_state_sampling = true;
 float g_use_seen_state_prob = 0.5f, g_sel_mult_base = 0.0f, g_sel_mult_scale = 1.0f;
+int g_num_groups = 2;
 long g_last_reuse_added = 0, g_last_examples = 0;
 }
 
@@ -595,6 +596,10 @@ void p3host_selfplay_set_policy(int init_state_sampling, float use_seen_state_pr
   g_sel_mult_base = sel_mult_base;
   g_sel_mult_scale = sel_mult_scale_factor;
 }
+// Number of game groups of subsequent p3host_selfplay_run calls (>= 2).  Each group has its own
+// engine instance and is either being advanced on the host or evaluated on the GPU; with G
+// groups up to G - 1 forward passes are in flight while one group is on the host.
+void p3host_selfplay_set_groups(int n) { g_num_groups = n < 2 ? 2 : (n > 8 ? 8 : n); }
 // reuse-buffer insertions and training examples written by the last p3host_selfplay_run
 long p3host_selfplay_last_reuse_added() { return g_last_reuse_added; }
 long p3host_selfplay_last_examples() { return g_last_examples; }
@@ -641,7 +646,6 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
                         int num_threads, int default_n, int default_k, int selected_n,
                         int selected_k, int max_moves, double seconds, int warmup_batches,
                         uint64_t seed, p3host_selfplay_stats* out, char* err) {
-  if (num_games < 2) num_games = 2;
   SelfPlayConfig cfg;
   cfg.default_n = default_n; cfg.default_k = default_k;
   cfg.selected_n = selected_n; cfg.selected_k = selected_k;
@@ -660,10 +664,12 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     recorder.reset(new GameRecorder(g_rec_dir, g_rec_gen, g_rec_worker, g_rec_flush_interval));
     cfg.recorder = recorder.get();
   }
-  Half halves[2];
+  const int NG = g_num_groups;
+  if (num_games < NG) num_games = NG;
+  std::vector<Half> halves(NG);
   const bool use_null = !engine_lib || !engine_lib[0];
-  for (int h = 0; h < 2; ++h) {
-    const int ng = num_games / 2 + (h == 0 ? num_games % 2 : 0);
+  for (int h = 0; h < NG; ++h) {
+    const int ng = num_games / NG + (h < num_games % NG ? 1 : 0);
     if (use_null) {
       halves[h].eval.reset(new NullEvaluator());
     } else {
@@ -681,8 +687,8 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     }
   }
   WorkerPool pool(num_threads > 0 ? num_threads : 1);
-  std::vector<p3hip_features> feats[2];
-  for (int h = 0; h < 2; ++h) feats[h].resize(halves[h].games.size());
+  std::vector<std::vector<p3hip_features>> feats(NG);
+  for (int h = 0; h < NG; ++h) feats[h].resize(halves[h].games.size());
 
   auto advance_half = [&](int h, bool deliver) {
     Half& H = halves[h];
@@ -696,7 +702,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
       H.eval->Load(g, feats[h][g]);
     });
   };
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NG; ++h) {
     Half* H = &halves[h];
     H->gpu = std::thread([H] {
       for (;;) {
@@ -739,10 +745,10 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   };
 
   int rc = 0;
-  advance_half(0, false);
-  request_run(0);
-  advance_half(1, false);
-  request_run(1);
+  for (int h = 0; h < NG; ++h) {
+    advance_half(h, false);
+    request_run(h);
+  }
   GameStats base;
   double base_gpu = 0, host_seconds = 0;
   long base_runs = 0;
@@ -750,7 +756,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   bool measuring = false;
   long iter = 0;
   for (;;) {
-    for (int h = 0; h < 2 && rc == 0; ++h) {
+    for (int h = 0; h < NG && rc == 0; ++h) {
       if (!wait_run(h)) {
         rc = 2;
         if (err) snprintf(err, 256, "engine run failed");
@@ -766,15 +772,15 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     ++iter;
     if (!measuring && iter >= warmup_batches) {
       totals(base);
-      base_gpu = halves[0].gpu_seconds + halves[1].gpu_seconds;
-      base_runs = halves[0].runs + halves[1].runs;
+      base_gpu = 0; base_runs = 0;
+      for (auto& H : halves) { base_gpu += H.gpu_seconds; base_runs += H.runs; }
       host_seconds = 0;
       t_start = std::chrono::steady_clock::now();
       measuring = true;
     }
     if (measuring && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= seconds) break;
   }
-  for (int h = 0; h < 2; ++h) wait_run(h);
+  for (int h = 0; h < NG; ++h) wait_run(h);
   double secs = measuring ? std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() : 0;
   for (auto& H : halves) {
     {
@@ -795,8 +801,9 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     out->moves = t.moves - base.moves;
     out->games = t.games - base.games;
     out->black_wins = t.black_wins - base.black_wins;
-    out->batches = halves[0].runs + halves[1].runs - base_runs;
-    out->gpu_seconds = halves[0].gpu_seconds + halves[1].gpu_seconds - base_gpu;
+    out->batches = -base_runs;
+    out->gpu_seconds = -base_gpu;
+    for (auto& H : halves) { out->batches += H.runs; out->gpu_seconds += H.gpu_seconds; }
     out->host_seconds = host_seconds;
     out->cache_hits = t.cache_hits - base.cache_hits;
   }

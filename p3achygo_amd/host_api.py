@@ -182,6 +182,13 @@ def set_policy(init_state_sampling: bool = True, use_seen_state_prob: float = 0.
     L.p3host_selfplay_set_policy(int(init_state_sampling), use_seen_state_prob, sel_mult_base, sel_mult_scale_factor)
 
 
+def set_groups(n: int) -> None:
+    """Game groups (engine instances) of subsequent selfplay_run calls; default 2."""
+    L = lib()
+    L.p3host_selfplay_set_groups.argtypes = [C.c_int]
+    L.p3host_selfplay_set_groups(n)
+
+
 def last_run_counters():
     """(reuse-buffer insertions, training examples written) of the last selfplay_run."""
     L = lib()

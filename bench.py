@@ -86,14 +86,11 @@ def main():
     ap.add_argument("--selfplay-seconds", type=float, default=8.0)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from p3achygo_amd import sharding
+    shard = sharding.shard_from_env()
+    rank, local_rank, world = shard.rank, shard.local_rank, shard.world
     import torch
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    sharding.init(shard)
     n_gpus = max(world, 1)
 
     from p3achygo_amd import engine, netspec
@@ -112,8 +109,7 @@ def main():
     def barrier():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        sharding.barrier(shard)
 
     for _ in range(args.warmup):
         eng.forward_resident(args.batch)
@@ -124,11 +120,8 @@ def main():
     eng.sync()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-        dist.barrier()
+    dt = sharding.max_over_ranks(shard, dt)
+    sharding.barrier(shard)
 
     total_flops, conv3_flops = eng.flops_per_position()
     eng.close()
@@ -143,10 +136,8 @@ def main():
         host_api.set_groups(3)   # three game groups: two forward passes in flight while one group is on the host
         st = host_api.selfplay_run(path, 3 * args.batch, threads, args.selfplay_seconds, default_n=32,
                                    default_k=5, selected_n=32, selected_k=5, warmup_batches=4,
-                                   seed=77 + rank, device=local_rank)
-        sp = torch.tensor([st.positions / st.seconds, st.moves / st.seconds], dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(sp, op=dist.ReduceOp.SUM)
+                                   seed=sharding.seed_for_rank(77, shard), device=local_rank)
+        sp = sharding.sum_over_ranks(shard, [st.positions / st.seconds, st.moves / st.seconds])
         selfplay = {"value": float(sp[0]), "unit": "positions/s", "moves_per_s": float(sp[1]),
                     "concurrent_games_per_gpu": 3 * args.batch, "batch": args.batch, "game_groups": 3,
                     "host_threads_per_gpu": threads, "seconds": st.seconds,
@@ -172,8 +163,7 @@ def main():
             roof["traffic_source"] = prof["source"]
         if n_gpus == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(path, pos)
-    if world > 1:
-        dist.barrier()
+    sharding.barrier(shard)
 
     if rank == 0:
         pps = n_gpus * args.batch * args.steps / dt
@@ -194,8 +184,7 @@ def main():
         }
         print(json.dumps(out))
     eng.close()
-    if world > 1:
-        dist.destroy_process_group()
+    sharding.finish(shard)
 
 
 if __name__ == "__main__":

@@ -84,7 +84,8 @@ typedef struct p3hip_engine p3hip_engine;
 
 /* p3hip_create flags */
 #define P3HIP_FLAG_NONE 0u
-#define P3HIP_FLAG_NO_GRAPH 1u      /* launch kernels eagerly instead of replaying a hipGraph */
+#define P3HIP_FLAG_NO_GRAPH 1u      /* reserved: kernels are always launched eagerly (17 launches of
+                                       0.05-0.4 ms per forward pass; launch cost is hidden) */
 #define P3HIP_FLAG_RUN_ALL_SLOTS 2u /* always run the full static batch (TRT behaviour,
                                        trt_engine.cc:238-304); default compacts to loaded slots */
 
@@ -126,8 +127,10 @@ int p3hip_sync(p3hip_engine* e);
  * [726..1525] score logits, [1526..1886] ownership, [1887] q6_err, [1888] gamma. */
 #define P3HIP_RAW_LEN 1889
 int p3hip_get_raw(p3hip_engine* e, int slot, float* out);
-/* Times `iters` launches of the dominant trunk kernel alone with HIP events on the
- * engine's stream; returns average milliseconds per launch (<0 on error) and writes the
+/* Times the dominant trunk kernel in place: runs `iters` forward passes over the resident
+ * batch with a HIP event pair on the engine's stream around every fused-block launch and
+ * returns the average milliseconds per launch (<0 on error; also <0 for layer-wise trunks,
+ * which have no fused block kernel); writes the
  * algorithmic FLOPs of the convs one launch executes (inner 3x3s + 1x1 reduce/expand,
  * unpadded 361 points). */
 double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,

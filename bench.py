@@ -89,6 +89,8 @@ def main():
     from p3achygo_amd import sharding
     shard = sharding.shard_from_env()
     rank, local_rank, world = shard.rank, shard.local_rank, shard.world
+    if os.environ.get("P3_BENCH_SINGLE_DEVICE"):   # rehearsal of the N > 1 path on a one-GPU box
+        local_rank = 0
     import torch
     sharding.init(shard)
     n_gpus = max(world, 1)

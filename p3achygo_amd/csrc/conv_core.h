@@ -108,7 +108,7 @@ struct Ring {
   int pf_slot;
   int slot;            // ring slot of the next macro-step to consume
   int tol;             // acquires left that must tolerate `extra` younger register loads/stores
-  int extra;           // 12, 24 or 48 (see ring_note_inflight)
+  int extra;           // 12, 24, 36 or 48 (see ring_note_inflight)
   unsigned long long wait_cycles;  // diagnostic builds: cycles spent in ring_acquire waits
   int dbg;             // diagnostic builds: bit0 = skip waits/barriers/prefetch (timing only)
 };
@@ -185,6 +185,9 @@ __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
     } else if (r.extra == 24) {
       if (G == 2) asm volatile("s_waitcnt vmcnt(26) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
       else asm volatile("s_waitcnt vmcnt(25) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
+    } else if (r.extra == 36) {
+      if (G == 2) asm volatile("s_waitcnt vmcnt(38) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
+      else asm volatile("s_waitcnt vmcnt(37) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
     } else {
       if (G == 2) asm volatile("s_waitcnt vmcnt(50) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
       else asm volatile("s_waitcnt vmcnt(49) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
@@ -202,7 +205,7 @@ __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
   return off;
 }
 
-// Call right after issuing `extra` (12, 24 or 48) ordinary vector-memory operations whose
+// Call right after issuing `extra` (12, 24, 36 or 48) ordinary vector-memory operations whose
 // completion should not be forced by the next D ring acquires (and nothing else since the
 // last ring_issue): the glds those acquires wait for are older than all of them.
 template <int RS>

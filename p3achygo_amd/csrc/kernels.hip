@@ -268,17 +268,34 @@ __global__ void __launch_bounds__(kWG, 2) k_conv1x1(Conv1x1Args a) {
   const int lg = wid / T::CG;
   const int lr = lane & 31;
 
+  // Staging is software-pipelined: the slice after the current one (next K slice, next output
+  // pass or next position) is fetched into registers while the current segment's MFMAs run,
+  // its BN+mish is applied in registers before the barrier that frees the act buffer.
+  constexpr int NIP = CIN / CB;
+  XRegs<G> xr;
+  stage_load<G>(xr, a.in, CIN, blockIdx.x * NPOS, a.npos, 0);
+  int pending_stores = 0;   // vector-memory ops of the previous epilogue that may still be in flight
   for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS) {
 #pragma unroll 1
     for (int cp = 0; cp < NCP; ++cp) {
       f32x16 acc[2][T::NT];
       acc_zero<G, CP>(acc);
 #pragma unroll 1
-      for (int ip = 0; ip < CIN / CB; ++ip) {
+      for (int ip = 0; ip < NIP; ++ip) {
+        if (PRE) stage_math<G>(xr, ip * G::NCH, a.scale, a.shift);
         lds_barrier();
-        stage_in<G, PRE>(smem, a.in, CIN, pos0, a.npos, ip * G::NCH, a.scale, a.shift);
+        stage_store<G, false>(smem, xr, ip * G::NCH, nullptr, nullptr);
+        int nip = ip + 1, npos0 = pos0;
+        if (nip == NIP) {
+          nip = 0;
+          if (cp + 1 == NCP) npos0 = pos0 + gridDim.x * NPOS;   // past the end: clamped to a valid position
+        }
+        stage_load<G>(xr, a.in, CIN, npos0, a.npos, nip * G::NCH);
+        ring_note_inflight(ring, pending_stores + kXLoads);
+        pending_stores = 0;
         conv_segment<G, CP, 1, 1>(ring, smem, acc);
       }
+      pending_stores = (EPI == 2) ? 0 : 24;
       if (EPI == 1) {
         epilogue_to_global<G, CP, true>(acc, a.out16, COUT, pos0, a.npos, cp * CP);
       } else if (EPI == 0) {
@@ -325,7 +342,7 @@ __global__ void __launch_bounds__(kWG, 2) k_conv1x1(Conv1x1Args a) {
 //                                        so inner layers stage without VALU work)
 //   res : out += acc                    (residual, in place)
 // =======================================================================================
-template <int KW, int CIN, int COUT>
+template <int KW, int CIN, int COUT, bool PRE, bool ACT, bool RES>
 __global__ void __launch_bounds__(kWG, 2) k_lconv(LConvArgs a) {
   constexpr int CB = 64, NPOS = 2, CP = 64;
   using G = Geo<NPOS, CB, KW>;
@@ -335,31 +352,45 @@ __global__ void __launch_bounds__(kWG, 2) k_lconv(LConvArgs a) {
   Ring<T::RS> ring;
   ring_init(ring, smem, a.wstream, a.nms_total, G::ACT_BYTES);
   lds_barrier();
+  constexpr int NIP = CIN / CB, NCP = COUT / CP;
+  XRegs<G> xr;   // software-pipelined staging, as in k_conv1x1
+  stage_load<G>(xr, a.in, CIN, blockIdx.x * NPOS, a.npos, 0);
+  int pending_stores = 0;
   for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS) {
 #pragma unroll 1
-    for (int cp = 0; cp < COUT / CP; ++cp) {
+    for (int cp = 0; cp < NCP; ++cp) {
       f32x16 acc[2][T::NT];
       acc_zero<G, CP>(acc);
 #pragma unroll 1
-      for (int ip = 0; ip < CIN / CB; ++ip) {
+      for (int ip = 0; ip < NIP; ++ip) {
+        if (PRE) stage_math<G>(xr, ip * G::NCH, a.scale_in, a.shift_in);
         lds_barrier();
-        if (a.pre) stage_in<G, true>(smem, a.in, CIN, pos0, a.npos, ip * G::NCH, a.scale_in, a.shift_in);
-        else stage_in<G, false>(smem, a.in, CIN, pos0, a.npos, ip * G::NCH, nullptr, nullptr);
+        stage_store<G, false>(smem, xr, ip * G::NCH, nullptr, nullptr);
+        int nip = ip + 1, npos0 = pos0;
+        if (nip == NIP) {
+          nip = 0;
+          if (cp + 1 == NCP) npos0 = pos0 + gridDim.x * NPOS;
+        }
+        stage_load<G>(xr, a.in, CIN, npos0, a.npos, nip * G::NCH);
+        ring_note_inflight(ring, pending_stores + kXLoads);
+        pending_stores = 0;
         conv_segment<G, CP, KW, KW * KW>(ring, smem, acc);
       }
-      if (a.act) {
-        EpiParams ep;
-        epi_params<G, CP>(ep, a.scale_out, a.shift_out, cp * CP);
+      pending_stores = 24;
+      if (ACT) {   // parameters are fetched one channel quad at a time: the prefetched slice stays in registers
+        const int c0 = cp * CP + cg_of<G, CP>() * 64 + (launder(threadIdx.x & 63) >> 5) * 4;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < 8; ++k) {
+          const f32x4 sc = *(const f32x4*)(a.scale_out + c0 + 8 * k), sh = *(const f32x4*)(a.shift_out + c0 + 8 * k);
 #pragma unroll
           for (int j = 0; j < T::NT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              acc[k >> 2][j][(k & 3) * 4 + i] = mish_f(acc[k >> 2][j][(k & 3) * 4 + i] * ep.sc[k][i] + ep.sh[k][i]);
+              acc[k >> 2][j][(k & 3) * 4 + i] = mish_f(acc[k >> 2][j][(k & 3) * 4 + i] * sc[i] + sh[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      if (a.res) epilogue_to_global<G, CP, true>(acc, a.out, COUT, pos0, a.npos, cp * CP);
-      else epilogue_to_global<G, CP, false>(acc, a.out, COUT, pos0, a.npos, cp * CP);
+      epilogue_to_global<G, CP, RES>(acc, a.out, COUT, pos0, a.npos, cp * CP);
     }
   }
   lds_barrier();
@@ -827,24 +858,34 @@ hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipS
   return hipErrorInvalidValue;
 }
 
-template <int KW, int CIN, int COUT>
+template <int KW, int CIN, int COUT, bool PRE, bool ACT, bool RES>
 static hipError_t launch_lconv_t(const LConvArgs& a, int grid, hipStream_t s) {
   using G = Geo<2, 64, KW>;
   constexpr size_t lds = G::ACT_BYTES + ring_bytes(64);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = set_lds(k_lconv<KW, CIN, COUT>, lds);
+    hipError_t e = set_lds(k_lconv<KW, CIN, COUT, PRE, ACT, RES>, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_lconv<KW, CIN, COUT>), dim3(grid), dim3(kWG), lds, s, a);
+  hipLaunchKernelGGL((k_lconv<KW, CIN, COUT, PRE, ACT, RES>), dim3(grid), dim3(kWG), lds, s, a);
   return hipGetLastError();
 }
 
+// the seven layer shapes of C=384 / C_b=192 btl and nbt blocks (engine.cpp build_plan)
 hipError_t launch_lconv(int kw, int cin, int cout, const LConvArgs& a, int grid, hipStream_t s) {
-  if (kw == 1 && cin == 384 && cout == 192) return launch_lconv_t<1, 384, 192>(a, grid, s);
-  if (kw == 3 && cin == 192 && cout == 192) return launch_lconv_t<3, 192, 192>(a, grid, s);
-  if (kw == 1 && cin == 192 && cout == 384) return launch_lconv_t<1, 192, 384>(a, grid, s);
+  const int f = (a.pre ? 4 : 0) | (a.act ? 2 : 0) | (a.res ? 1 : 0);
+  if (kw == 1 && cin == 384 && cout == 192) {
+    if (f == 6) return launch_lconv_t<1, 384, 192, true, true, false>(a, grid, s);    // btl reduce
+    if (f == 4) return launch_lconv_t<1, 384, 192, true, false, false>(a, grid, s);   // nbt reduce
+  } else if (kw == 3 && cin == 192 && cout == 192) {
+    if (f == 2) return launch_lconv_t<3, 192, 192, false, true, false>(a, grid, s);   // btl inner
+    if (f == 6) return launch_lconv_t<3, 192, 192, true, true, false>(a, grid, s);    // nbt conv1 / conv3
+    if (f == 1) return launch_lconv_t<3, 192, 192, false, false, true>(a, grid, s);   // nbt conv2 / conv4
+  } else if (kw == 1 && cin == 192 && cout == 384) {
+    if (f == 1) return launch_lconv_t<1, 192, 384, false, false, true>(a, grid, s);   // btl expand
+    if (f == 5) return launch_lconv_t<1, 192, 384, true, false, true>(a, grid, s);    // nbt expand
+  }
   return hipErrorInvalidValue;
 }
 

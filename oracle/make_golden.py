@@ -95,5 +95,6 @@ if __name__ == "__main__":
     dump_nn("test_b3c256nbt", 3, 17)
     dump_nn("test_b3c384btl3", 3, 18)
     dump_nn("test_b3c384nbt", 3, 19)
+    dump_nn("test_b3c192classic", 3, 20)
     dump_nn("b8c128nbt", 2, 14)
     dump_nn("b12c256btl3", 2, 15)

@@ -220,22 +220,25 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
   const WeightFile& wf = e->wf;
   const int C = wf.C, Cb = wf.Cb;
   const bool fused = (C == 256 && Cb == 128) || (C == 128 && Cb == 64);
-  const bool layerwise = (C == 384 && Cb == 192);
-  if (!(fused || layerwise) || wf.H != 32 || (wf.V != 32 && wf.V != 48 && wf.V != 64 && wf.V != 80) ||
-      wf.btype > 1 || (wf.btype == 0 && (wf.inner < 1 || wf.inner > 3))) {
-    e->err = "unsupported architecture for the HIP engine (need (C, Cb) in {(128,64), (256,128), (384,192)}, "
-             "H=32, V in {32,48,64,80}, btl with 1-3 inner layers or nbt)";
+  const bool classic = wf.btype == 2 && C == 192 && wf.inner == 2;   // b15c192_classic
+  const bool bottleneck_ok = wf.btype == 1 || (wf.btype == 0 && wf.inner >= 1 && wf.inner <= 3);
+  const bool layerwise = (C == 384 && Cb == 192 && bottleneck_ok) || classic;
+  const bool v_ok = wf.V == 32 || wf.V == 48 || wf.V == 64 || wf.V == 80;
+  if (!((fused && bottleneck_ok) || layerwise) || wf.H != 32 || !v_ok) {
+    e->err = "unsupported architecture for the HIP engine (need (C, Cb) in {(128,64), (256,128), (384,192)} with "
+             "btl (1-3 inner layers) or nbt blocks, or C=192 classic blocks of two convs; H=32, V in {32,48,64,80})";
     return false;
   }
   // slice width of the per-position kernels that stage C channels (k_conv1x1 family)
-  const int CB = layerwise ? 128 : Cb;
+  const int CB = classic ? 64 : (layerwise ? 128 : Cb);
+  const int CPI = classic ? 64 : 128;   // output pass width of the init conv
   // init conv
   {
     std::vector<_Float16> s;
     const Tensor& w = wf.get("init_conv.w");  // [5][5][15][C]
-    for (int cp = 0; cp < C / 128; ++cp)
-      pack_segment(s, w.data, 25, 28, 15, C, 0, 16, cp * 128, 128);
-    e->init_stream_off = add_stream(ar, s, e->init_nms, 128);
+    for (int cp = 0; cp < C / CPI; ++cp)
+      pack_segment(s, w.data, 25, 28, 15, C, 0, 16, cp * CPI, CPI);
+    e->init_stream_off = add_stream(ar, s, e->init_nms, CPI);
     e->game_w_off = ar.add(wf.get("init_game.w").data, 8 * C * 4);
     e->game_b_off = ar.add(wf.get("init_game.b").data, C * 4);
   }
@@ -270,7 +273,7 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
       bp.dense_bias_off = ar.add(wf.get(p + ".dense.b").data, kNLoc * 4);
     } else if (layerwise) {
       bp.kind = 4;
-      const int nconv = (wf.btype == 0) ? wf.inner + 2 : 6;
+      const int nconv = classic ? 2 : ((wf.btype == 0) ? wf.inner + 2 : 6);
       for (int j = 0; j < nconv; ++j) bp.bn[j] = fold_bn(ar, wf, p + ".bn" + std::to_string(j));
       auto add_layer = [&](int j, int kw, int cin, int cout, int pre_bn, int act_bn, int res, int in_buf, int out_buf) {
         LayerPlan lp{kw, cin, cout, pre_bn, act_bn, res, in_buf, out_buf};
@@ -280,7 +283,10 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
         lp.stream_off = add_stream(ar, s, lp.nms, 64);
         bp.layers.push_back(lp);
       };
-      if (wf.btype == 0) {   // btl: every inner input is produced already activated
+      if (classic) {         // x + conv3(act1(conv3(act0(x)))), model.py:330-368
+        add_layer(0, 3, C, C, 0, 1, 0, 0, 1);
+        add_layer(1, 3, C, C, -1, -1, 1, 1, 0);
+      } else if (wf.btype == 0) {   // btl: every inner input is produced already activated
         add_layer(0, 1, C, Cb, 0, 1, 0, 0, 1);
         int cur = 1;
         for (int j = 1; j <= wf.inner; ++j) {
@@ -364,7 +370,7 @@ p3::BlockArgs block_args(p3hip_engine* e, const BlockPlan& bp, int npos) {
 bool enqueue_forward(p3hip_engine* e, int npos) {
   const WeightFile& wf = e->wf;
   const int C = wf.C;
-  const int npw = (C >= 256) ? 1 : 2;
+  const int npw = (C >= 256) ? 1 : 2;   // positions per workgroup of the k_conv1x1 family (CB = 64: two)
   hipStream_t s = e->stream;
   {
     p3::InitArgs a{};
@@ -610,6 +616,7 @@ void p3hip_flops_per_position(const p3hip_engine* e, double* total, double* conv
     if (w.is_broadcast(i)) mac += L * 2 * C * C + C * L * L;
     else if (w.btype == 0) { mac += L * 2 * C * Cb; mac3 += L * w.inner * 9 * Cb * Cb; }
     else if (w.btype == 1) { mac += L * 2 * C * Cb; mac3 += L * 4 * 9 * Cb * Cb; }
+    else { mac3 += L * w.inner * 9 * C * C; }
   }
   mac += L * 3 * C * H + L * H * 5 + 2 * H * H + 2 * H * 4 + 2 * H * V * 2 + V * (14 + 51 + 1) +
          (2 * H + 1) * V + 800 * V;

@@ -148,10 +148,10 @@ struct FeatOff {  // byte offsets inside p3hip_features (include/p3hip.h)
                        three = 1138, ladder = 1499, size = 1860;
 };
 
-template <int C>
+template <int C, int CP = 128>
 __global__ void __launch_bounds__(kWG, 2) k_init(InitArgs a) {
   using G = Geo<1, 16, 5>;
-  constexpr int CP = 128;
+  static_assert(C % CP == 0, "output passes");
   using T = Tiling<G, CP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr uint32_t kRingOff = G::ACT_BYTES;
@@ -426,10 +426,14 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
 
   for (int pos = blockIdx.x; pos < a.npos; pos += gridDim.x) {
 #pragma unroll 1
-    for (int half = 0; half < C / CH; ++half) {
+    for (int half = 0; half < (C + CH - 1) / CH; ++half) {
+      // channels of this pass (the last pass of C = 192 has 64: its upper channel tiles idle
+      // but still take part in the ring's barriers)
+      const int nch = (C - half * CH) < CH ? (C - half * CH) : CH;
+      const bool ct_active = ct * 32 < nch;
       lds_barrier();
       // ---- transpose-stage t[pos][cblk][loc][8] -> Tt[c][i] --------------------------
-      for (int it = threadIdx.x; it < (CH / 8) * kNLoc; it += kWG) {
+      for (int it = threadIdx.x; it < (nch / 8) * kNLoc; it += kWG) {
         const int kb = it / kNLoc, loc = it - kb * kNLoc;
         const h8 v = *(const h8*)(a.t + ((size_t)pos * (C / 8) + half * (CH / 8) + kb) * (kNLoc * 8) + loc * 8);
 #pragma unroll
@@ -450,9 +454,12 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
           const h8 av = *(const h8*)(smem + a_base + q * 32);
           const h8 b0 = *(const h8*)(smem + wk + b_off);
           const h8 b1 = *(const h8*)(smem + wk + b_off + 512);
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
+          if (ct_active) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
+          }
         }
+        if (!ct_active) continue;
         // epilogue: rows = channel (regs), cols = j (lanes)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -813,7 +820,10 @@ static hipError_t set_lds(K kernel, size_t lds) {
 hipError_t launch_init(int C, const InitArgs& a, int grid, hipStream_t s) {
   using G = Geo<1, 16, 5>;
   constexpr size_t lds = G::ACT_BYTES + ring_bytes(128);
-  if (C == 384) {
+  if (C == 192) {
+    constexpr size_t lds64 = G::ACT_BYTES + ring_bytes(64);
+    hipLaunchKernelGGL((k_init<192, 64>), dim3(grid), dim3(kWG), lds64, s, a);
+  } else if (C == 384) {
     hipLaunchKernelGGL((k_init<384>), dim3(grid), dim3(kWG), lds, s, a);
   } else if (C == 256) {
     hipLaunchKernelGGL((k_init<256>), dim3(grid), dim3(kWG), lds, s, a);
@@ -842,7 +852,11 @@ static hipError_t launch_conv1x1_t(const Conv1x1Args& a, int grid, hipStream_t s
 }
 
 hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipStream_t s) {
-  if (C == 384) {
+  if (C == 192) {
+    if (which == 0) return launch_conv1x1_t<192, 192, true, 0>(a, grid, s);
+    if (which == 1) return launch_conv1x1_t<192, 192, false, 1>(a, grid, s);
+    if (which == 2) return launch_conv1x1_t<192, 96, false, 2>(a, grid, s);
+  } else if (C == 384) {
     if (which == 0) return launch_conv1x1_t<384, 384, true, 0>(a, grid, s);
     if (which == 1) return launch_conv1x1_t<384, 384, false, 1>(a, grid, s);
     if (which == 2) return launch_conv1x1_t<384, 96, false, 2>(a, grid, s);
@@ -896,10 +910,13 @@ hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s) {
     hipError_t e = set_lds(k_bdense<256>, lds);
     if (e == hipSuccess) e = set_lds(k_bdense<128>, lds);
     if (e == hipSuccess) e = set_lds(k_bdense<384>, lds);
+    if (e == hipSuccess) e = set_lds(k_bdense<192>, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  if (C == 384) {
+  if (C == 192) {
+    hipLaunchKernelGGL((k_bdense<192>), dim3(grid), dim3(kWG), lds, s, a);
+  } else if (C == 384) {
     hipLaunchKernelGGL((k_bdense<384>), dim3(grid), dim3(kWG), lds, s, a);
   } else if (C == 256) {
     hipLaunchKernelGGL((k_bdense<256>), dim3(grid), dim3(kWG), lds, s, a);

@@ -78,6 +78,7 @@ CONFIGS: Dict[str, NetConfig] = {
         NetConfig("test_b3c256nbt", 3, 256, 128, 32, 80, 3, 2, "nbt"),
         NetConfig("test_b3c384btl3", 3, 384, 192, 32, 80, 3, 3, "btl"),
         NetConfig("test_b3c384nbt", 3, 384, 192, 32, 64, 3, 2, "nbt"),
+        NetConfig("test_b3c192classic", 3, 192, 64, 32, 80, 3, 2, "classic"),
     ]
 }
 

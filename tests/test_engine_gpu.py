@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 2e-2
 PROB_TOL = 2e-3
-NETS = ["test_b3c128btl2", "test_b3c128nbt", "test_b3c256btl1", "test_b3c256nbt", "test_b3c384btl3", "test_b3c384nbt", "b8c128nbt",
+NETS = ["test_b3c128btl2", "test_b3c128nbt", "test_b3c256btl1", "test_b3c256nbt", "test_b3c384btl3", "test_b3c384nbt", "test_b3c192classic", "b8c128nbt",
         "b12c256btl3"]
 
 

@@ -424,20 +424,41 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
   const int ct = wid >> 1;       // channel tile (32 channels) 0..3
   const int lr = lane & 31, h = lane >> 5;
 
+  // Staging is software-pipelined like the conv kernels': the 12 16-byte loads of the next
+  // 128-channel pass (next half or next position) are issued before the current pass's K loop
+  // and scattered (transposed) into LDS after the barrier that ends it.
+  using GS = Geo<1, 128, 1>;   // thread -> (channel block, 12 board points) map of stage_load
+  constexpr int NHALF = (C + CH - 1) / CH;
+  XRegs<GS> xr;
+  stage_load<GS>(xr, a.t, C, blockIdx.x, a.npos, 0);
   for (int pos = blockIdx.x; pos < a.npos; pos += gridDim.x) {
 #pragma unroll 1
-    for (int half = 0; half < (C + CH - 1) / CH; ++half) {
+    for (int half = 0; half < NHALF; ++half) {
       // channels of this pass (the last pass of C = 192 has 64: its upper channel tiles idle
       // but still take part in the ring's barriers)
       const int nch = (C - half * CH) < CH ? (C - half * CH) : CH;
       const bool ct_active = ct * 32 < nch;
       lds_barrier();
       // ---- transpose-stage t[pos][cblk][loc][8] -> Tt[c][i] --------------------------
-      for (int it = threadIdx.x; it < (nch / 8) * kNLoc; it += kWG) {
-        const int kb = it / kNLoc, loc = it - kb * kNLoc;
-        const h8 v = *(const h8*)(a.t + ((size_t)pos * (C / 8) + half * (CH / 8) + kb) * (kNLoc * 8) + loc * 8);
+      {
+        const int combo = threadIdx.x >> 5, l32 = threadIdx.x & 31;   // combo = channel block of this pass
+        if (combo * 8 < nch) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) *(_Float16*)(smem + (kb * 8 + e) * kTtStride + loc * 2) = v[e];
+          for (int i = 0; i < kXLoads; ++i) {
+            const int loc = l32 + 32 * i;
+            if (loc >= kNLoc) continue;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *(_Float16*)(smem + (combo * 8 + e) * kTtStride + loc * 2) = xr.v[i][e];
+          }
+        }
+      }
+      {
+        int nhalf = half + 1, npos = pos;
+        if (nhalf == NHALF) { nhalf = 0; npos = pos + gridDim.x; }
+        // channel blocks past C (second pass of C = 192) are clamped to a valid block and ignored
+        int cblk0 = nhalf * (CH / 8);
+        stage_load<GS>(xr, a.t, C, npos, a.npos, cblk0 + ((threadIdx.x >> 5) * 8 < C - nhalf * CH ? 0 : -(int)(threadIdx.x >> 5)));
+        ring_note_xloads(ring);
       }
 #pragma unroll 1
       for (int jp = 0; jp < 3; ++jp) {

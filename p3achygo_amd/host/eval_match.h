@@ -20,9 +20,12 @@ namespace p3 {
 
 constexpr float kResignThreshold = -0.92f;   // eval.cc:28
 
-struct EvalPlayerConfig {   // PlayerSearchConfig (player_config.h:20-108), parallel-search subset
+struct EvalPlayerConfig {   // PlayerSearchConfig (player_config.h:20-108)
   int n = 128;                   // visit budget per move
-  int num_threads_per_game = 8;  // leaves per round
+  // > 1: parallel mcts::Search with this many leaves per round; 1: the legacy path,
+  // GumbelEvaluator::SearchRootPuct with LCB move choice (eval.cc:99-101,262-281, use_puct /
+  // use_lcb defaults of player_config.h:29,44)
+  int num_threads_per_game = 8;
   float c_puct = 1.0f, c_puct_visit_scaling = 0.45f, root_fpu = 0.2f;
   bool var_scale_cpuct = false;
   int var_scale_prior_visits = 0;
@@ -45,18 +48,24 @@ class EvalGame {
   int Step() {
     for (;;) {
       if (done_) return 0;
-      const int n = search_.Step();
-      if (n > 0) return n;
+      if (parallel_) {
+        const int n = search_.Step();
+        if (n > 0) return n;
+      } else if (puct_.Step() == GumbelSearch::Status::kNeedEval) {
+        return 1;
+      }
       FinishMove();
     }
   }
   void FillEval(int i, p3hip_features* f) {
     sym_[i] = RandomSymmetry(prob_.prng());
-    FillFeatures(search_.eval_pos(i), search_.eval_color(i), sym_[i], f);
+    if (parallel_) FillFeatures(search_.eval_pos(i), search_.eval_color(i), sym_[i], f);
+    else FillFeatures(*puct_.eval_game(), puct_.eval_color(), sym_[i], f);
   }
   void Deliver(int i, p3hip_result& r) {
     UnapplySymmetry(sym_[i], &r);
-    search_.Deliver(i, r);
+    if (parallel_) search_.Deliver(i, r);
+    else puct_.Resume(r);
   }
   // +1 cur won, -1 cand won, 0 draw
   int cur_result() const {
@@ -82,20 +91,32 @@ class EvalGame {
     p.puct.root_fpu = cfg_[side].root_fpu;
     p.puct.enable_var_scaling = cfg_[side].var_scale_cpuct;
     p.puct.var_scale_prior_visits = cfg_[side].var_scale_prior_visits;
-    search_.Begin(&game_, &pool_[side], tree_[side], color_, p);
+    parallel_ = cfg_[side].num_threads_per_game > 1;   // UsesParallelSearch, eval.cc:99-101
+    if (parallel_) {
+      search_.Begin(&game_, &pool_[side], tree_[side], color_, p);
+    } else {
+      p.puct.kind = PuctRootSelection::kLcb;
+      puct_.BeginPuct(&game_, &pool_[side], tree_[side], color_, cfg_[side].n, p.puct, /*tau=*/1.0f, &prob_);
+    }
   }
   void FinishMove() {
     const int side = color_ == kBlack ? 0 : 1;
-    const ParallelSearchResult& r = search_.result();
-    visits_ += r.num_visits;
-    collisions_ += r.num_collisions;
+    Loc move;
+    if (parallel_) {
+      const ParallelSearchResult& r = search_.result();
+      visits_ += r.num_visits;
+      collisions_ += r.num_collisions;
+      move = r.move;
+    } else {
+      visits_ += puct_.result().visits;
+      move = puct_.result().mcts_move;
+    }
     if (VOutcome(tree_[side]) < kResignThreshold) {   // eval.cc:277-282
       resigned_ = true;
       winner_ = Opp(color_);
       done_ = true;
       return;
     }
-    const Loc move = r.move;
     game_.PlayMove(move, color_);
     color_ = Opp(color_);
     for (int s = 0; s < 2; ++s) {   // both trees follow the move (eval.cc:318-352)
@@ -123,6 +144,8 @@ class EvalGame {
   TreeNode* tree_[2];
   Color color_ = kBlack;
   BatchSearch search_;
+  GumbelSearch puct_;
+  bool parallel_ = true;
   Symmetry sym_[64];
   bool done_ = false, resigned_ = false;
   Color winner_ = kEmpty;

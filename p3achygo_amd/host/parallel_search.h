@@ -21,73 +21,10 @@
 #include <vector>
 
 #include "board.h"
-#include "search.h"
+#include "search.h"   // includes confidence bounds (Lcb / Ucb)
 
 namespace p3 {
 
-
-// ---- Student-t quantiles for the confidence bounds (tree.cc:14-40: boost students_t) ---------
-inline double BetaCf(double a, double b, double x) {   // continued fraction of I_x(a, b)
-  const double tiny = 1e-300;
-  double qab = a + b, qap = a + 1, qam = a - 1, c = 1, d = 1 - qab * x / qap;
-  if (std::abs(d) < tiny) d = tiny;
-  d = 1 / d;
-  double h = d;
-  for (int m = 1; m <= 500; ++m) {
-    const int m2 = 2 * m;
-    double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
-    d = 1 + aa * d; if (std::abs(d) < tiny) d = tiny;
-    c = 1 + aa / c; if (std::abs(c) < tiny) c = tiny;
-    d = 1 / d; h *= d * c;
-    aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
-    d = 1 + aa * d; if (std::abs(d) < tiny) d = tiny;
-    c = 1 + aa / c; if (std::abs(c) < tiny) c = tiny;
-    d = 1 / d;
-    const double del = d * c;
-    h *= del;
-    if (std::abs(del - 1) < 1e-15) break;
-  }
-  return h;
-}
-inline double RegIncBeta(double a, double b, double x) {
-  if (x <= 0) return 0;
-  if (x >= 1) return 1;
-  const double bt = std::exp(std::lgamma(a + b) - std::lgamma(a) - std::lgamma(b) + a * std::log(x) + b * std::log(1 - x));
-  return x < (a + 1) / (a + b + 2) ? bt * BetaCf(a, b, x) / a : 1 - bt * BetaCf(b, a, 1 - x) / b;
-}
-// upper-tail quantile: t with P(T_nu > t) = p  (0 < p < 0.5)
-inline double StudentTUpperQuantile(double nu, double p) {
-  auto upper = [&](double t) { return 0.5 * RegIncBeta(nu / 2, 0.5, nu / (nu + t * t)); };
-  double lo = 0, hi = 1;
-  while (upper(hi) > p) hi *= 2;
-  for (int i = 0; i < 200; ++i) {
-    const double mid = 0.5 * (lo + hi);
-    (upper(mid) > p ? lo : hi) = mid;
-  }
-  return 0.5 * (lo + hi);
-}
-constexpr float kLcbAlpha = 0.05f;   // tree.cc:15
-inline float CachedTQuantile(int v) {   // tree.cc:16-33: two-sided alpha = 0.05, dof 1..1000
-  static const std::array<float, 1000> table = [] {
-    std::array<float, 1000> t;
-    for (int i = 1; i <= 1000; ++i) t[i - 1] = (float)StudentTUpperQuantile(i, kLcbAlpha / 2);
-    return t;
-  }();
-  if (v < 1) return table[0];
-  if (v < 1000) return table[v - 1];
-  return table.back();
-}
-inline float VVar(const TreeNode* n) { return !n || n->n < 3 ? kMaxQ : n->v_var; }   // tree.h:110-112
-inline std::pair<float, float> ConfidenceInterval(const TreeNode* node, int a) {   // tree.cc:42-55
-  const float n = (float)node->child_visits(a);
-  const TreeNode* ch = node->child(a);
-  if (!ch || n < 2) return {-1e6f + n, 1e6f - n};
-  const float stddev = std::sqrt(VVar(ch) / n);
-  const float z = CachedTQuantile((int)n - 1);
-  return {Q(node, a) - z * stddev, Q(node, a) + z * stddev};
-}
-inline float Lcb(const TreeNode* node, int a) { return ConfidenceInterval(node, a).first; }
-inline float Ucb(const TreeNode* node, int a) { return ConfidenceInterval(node, a).second; }
 
 // ---- PUCT scores, top-4 (search_policy.h:159-351, IdentityQ / IdentityN) ---------------------
 inline void PuctScoresAll(const TreeNode* node, const PuctParams& pp, bool is_root, float* scores) {

@@ -19,6 +19,7 @@
 #pragma once
 #include <algorithm>
 #include <cfloat>
+#include <array>
 #include <cmath>
 #include <memory>
 #include <vector>
@@ -190,6 +191,69 @@ inline void EvaluateTerminal(const Scores& s, TreeNode* node, Color c, Color roo
 }
 
 // ---- non-root PUCT (search_policy.h:159-368, IdentityQ / IdentityN) -----------------
+// ---- confidence bounds: Student-t quantiles (tree.cc:14-40 uses boost students_t) -------------
+inline double BetaCf(double a, double b, double x) {   // continued fraction of I_x(a, b)
+  const double tiny = 1e-300;
+  double qab = a + b, qap = a + 1, qam = a - 1, c = 1, d = 1 - qab * x / qap;
+  if (std::abs(d) < tiny) d = tiny;
+  d = 1 / d;
+  double h = d;
+  for (int m = 1; m <= 500; ++m) {
+    const int m2 = 2 * m;
+    double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+    d = 1 + aa * d; if (std::abs(d) < tiny) d = tiny;
+    c = 1 + aa / c; if (std::abs(c) < tiny) c = tiny;
+    d = 1 / d; h *= d * c;
+    aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+    d = 1 + aa * d; if (std::abs(d) < tiny) d = tiny;
+    c = 1 + aa / c; if (std::abs(c) < tiny) c = tiny;
+    d = 1 / d;
+    const double del = d * c;
+    h *= del;
+    if (std::abs(del - 1) < 1e-15) break;
+  }
+  return h;
+}
+inline double RegIncBeta(double a, double b, double x) {
+  if (x <= 0) return 0;
+  if (x >= 1) return 1;
+  const double bt = std::exp(std::lgamma(a + b) - std::lgamma(a) - std::lgamma(b) + a * std::log(x) + b * std::log(1 - x));
+  return x < (a + 1) / (a + b + 2) ? bt * BetaCf(a, b, x) / a : 1 - bt * BetaCf(b, a, 1 - x) / b;
+}
+// upper-tail quantile: t with P(T_nu > t) = p  (0 < p < 0.5)
+inline double StudentTUpperQuantile(double nu, double p) {
+  auto upper = [&](double t) { return 0.5 * RegIncBeta(nu / 2, 0.5, nu / (nu + t * t)); };
+  double lo = 0, hi = 1;
+  while (upper(hi) > p) hi *= 2;
+  for (int i = 0; i < 200; ++i) {
+    const double mid = 0.5 * (lo + hi);
+    (upper(mid) > p ? lo : hi) = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+constexpr float kLcbAlpha = 0.05f;   // tree.cc:15
+inline float CachedTQuantile(int v) {   // tree.cc:16-33: two-sided alpha = 0.05, dof 1..1000
+  static const std::array<float, 1000> table = [] {
+    std::array<float, 1000> t;
+    for (int i = 1; i <= 1000; ++i) t[i - 1] = (float)StudentTUpperQuantile(i, kLcbAlpha / 2);
+    return t;
+  }();
+  if (v < 1) return table[0];
+  if (v < 1000) return table[v - 1];
+  return table.back();
+}
+inline float VVar(const TreeNode* n) { return !n || n->n < 3 ? kMaxQ : n->v_var; }   // tree.h:110-112
+inline std::pair<float, float> ConfidenceInterval(const TreeNode* node, int a) {   // tree.cc:42-55
+  const float n = (float)node->child_visits(a);
+  const TreeNode* ch = node->child(a);
+  if (!ch || n < 2) return {-1e6f + n, 1e6f - n};
+  const float stddev = std::sqrt(VVar(ch) / n);
+  const float z = CachedTQuantile((int)n - 1);
+  return {Q(node, a) - z * stddev, Q(node, a) + z * stddev};
+}
+inline float Lcb(const TreeNode* node, int a) { return ConfidenceInterval(node, a).first; }
+inline float Ucb(const TreeNode* node, int a) { return ConfidenceInterval(node, a).second; }
+
 // Public ComputeImprovedPolicy(node, n) / ComputeKLD of the reference (gumbel.cc:172-204),
 // used by the self-play loop for its pre-/post-search KL statistics.
 inline float VMixedOf(const TreeNode* node) {   // gumbel.cc:68-87
@@ -218,7 +282,9 @@ inline float ComputeKLD(const float* target, const float* prior) {
   return (float)kld;
 }
 
+enum class PuctRootSelection { kVisitCount = 0, kLcb = 1, kVisitCountSample = 2 };   // search_policy.h:18-22
 struct PuctParams {
+  PuctRootSelection kind = PuctRootSelection::kVisitCountSample;   // self-play's fast moves
   float c_puct = 1.0f, c_puct_visit_scaling = 0.45f;
   bool enable_var_scaling = false;
   int var_scale_prior_visits = 0;
@@ -539,7 +605,17 @@ class GumbelSearch {
       res_.pi_improved[a] = total > 0 ? counts[a] / total : 0.0f;
       if (counts[a] > counts[amax]) amax = a;
     }
-    int mv = p_.tau > 0.0f ? amax : SampleFromPolicy(res_.pi_improved, p_.tau);
+    int mv = amax;   // gumbel.cc:628-643
+    if (puct_pp_.kind == PuctRootSelection::kLcb) {
+      std::array<std::pair<int, float>, kNumMoves> lcbs;
+      for (int a = 0; a < kNumMoves; ++a) lcbs[a] = {a, Lcb(root_, a)};
+      std::stable_sort(lcbs.begin(), lcbs.end(), [](const auto& x, const auto& y) { return y.second < x.second; });
+      mv = kPassEncoding;
+      for (const auto& al : lcbs)
+        if (root_pos_.board.IsValidMove(MoveLoc(al.first), color_)) { mv = al.first; break; }
+    } else if (puct_pp_.kind == PuctRootSelection::kVisitCountSample) {
+      mv = p_.tau > 0.0f ? amax : SampleFromPolicy(res_.pi_improved, p_.tau);   // (sic) the reference's inverted test
+    }
     res_.mcts_move = MoveLoc(mv);
     res_.visits = visits_spent_;
     res_.kld = 0;

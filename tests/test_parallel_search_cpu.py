@@ -66,3 +66,13 @@ def test_eval_match_null_engines(built):
     assert st.moves == 6 * 30 and st.resignations == 0          # uniform nets never resign or pass out early
     assert st.visits >= 16 * st.moves and st.positions > 0 and st.batches > 0
     assert st.positions <= st.visits + st.moves
+
+
+def test_eval_match_legacy_single_thread_path(built):
+    """num_threads_per_game = 1 takes GumbelEvaluator::SearchRootPuct with LCB move choice
+    (eval.cc:99-101,262-281): one evaluation per step, n visits per move."""
+    st = host_api.eval_match(None, None, num_games=4, visits_per_move=12, leaves_per_round=1, max_moves=16,
+                             num_threads=2, seed=9)
+    assert st.games == 4 and st.cur_wins + st.cand_wins + st.draws == 4 and st.moves == 4 * 16
+    assert st.visits == 12 * st.moves and st.collisions == 0
+    assert st.positions <= st.visits + st.moves

@@ -136,14 +136,21 @@ def main():
         cpus = len(os.sched_getaffinity(0))
         threads = max(2, min(16, cpus // max(world, 1)))
         host_api.set_groups(3)   # three game groups: two forward passes in flight while one group is on the host
-        st = host_api.selfplay_run(path, 3 * args.batch, threads, args.selfplay_seconds, default_n=32,
-                                   default_k=5, selected_n=32, selected_k=5, warmup_batches=4,
-                                   seed=sharding.seed_for_rank(77, shard), device=local_rank)
-        sp = sharding.sum_over_ranks(shard, [st.positions / st.seconds, st.moves / st.seconds])
+        rates, sp_err, secs = [0.0, 0.0], None, 0.0
+        try:   # a side measurement must never cost the headline line
+            st = host_api.selfplay_run(path, 3 * args.batch, threads, args.selfplay_seconds, default_n=32,
+                                       default_k=5, selected_n=32, selected_k=5, warmup_batches=4,
+                                       seed=sharding.seed_for_rank(77, shard), device=local_rank)
+            rates, secs = [st.positions / st.seconds, st.moves / st.seconds], st.seconds
+        except Exception as ex:   # noqa: BLE001
+            sp_err = repr(ex)
+        sp = sharding.sum_over_ranks(shard, rates)
         selfplay = {"value": float(sp[0]), "unit": "positions/s", "moves_per_s": float(sp[1]),
                     "concurrent_games_per_gpu": 3 * args.batch, "batch": args.batch, "game_groups": 3,
-                    "host_threads_per_gpu": threads, "seconds": st.seconds,
+                    "host_threads_per_gpu": threads, "seconds": secs,
                     "gumbel": "n=32 (default k<=5, selected k=5)", "includes": "host MCTS + PCIe + engine"}
+        if sp_err:
+            selfplay["error"] = sp_err
     eng = engine.create_engine(engine.kind_from_engine_path(path), path, args.batch, 1, device=local_rank)
     eng.load_all(pos)
     eng.upload()
@@ -164,7 +171,10 @@ def main():
             roof["algorithmic_bytes_per_launch"] = prof["algorithmic_bytes_per_launch"]
             roof["traffic_source"] = prof["source"]
         if n_gpus == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(path, pos)
+            try:
+                cpu = cpu_baseline(path, pos)
+            except Exception as ex:   # noqa: BLE001
+                cpu = {"error": repr(ex)}
     sharding.barrier(shard)
 
     if rank == 0:

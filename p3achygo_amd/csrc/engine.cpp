@@ -356,6 +356,7 @@ int grid_for(const p3hip_engine* e, int npos, int npos_per_wg) {
 p3::BlockArgs block_args(p3hip_engine* e, const BlockPlan& bp, int npos) {
   p3::BlockArgs a{};
   a.x = e->d_x;
+  a.t = e->d_t;
   a.npos = npos;
   a.wstream = e->d_arena + bp.stream_off;
   a.nms_total = bp.nms;

@@ -26,6 +26,7 @@ constexpr int kMaxBlockLayers = 8;
 
 struct BlockArgs {
   _Float16* x;          // residual stream, updated in place
+  _Float16* t;          // nbt: scratch for the inner residual stream [pos][CB/8][361][8]
   int npos;
   const void* wstream;  // packed weight stream of this block
   int nms_total;        // its length in 8 KiB macro-steps

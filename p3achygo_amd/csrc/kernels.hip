@@ -90,26 +90,34 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
       epilogue_layer16<G, CB, NT>(smem, acc, a.scale[L + 1], a.shift[L + 1]);
       P3_STAMP(11);
     } else {
-      // nbt: keep the raw inner residual t in registers (fp32, same tile as acc)
-      f32x4 t[4][NT];
+      // nbt: the raw inner residual stream t is parked in HBM scratch (fp16, as the reference's
+      // fp16 engine keeps it) instead of 96 fp32 registers per lane: it is written once after
+      // the reduce conv, read back after the second conv of each pair, and t' = t + conv(...) is
+      // written back once.
+      ResRegs16<NT> tr;
+      residual_addr16<G, CB, NT>(tr, CB, pos0, a.npos, 0);
+      epilogue_store16<false, NT>(acc, tr, a.t);
+      epilogue_layer16<G, CB, NT>(smem, acc, a.scale[1], a.shift[1]);
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) t[ct][j] = acc[ct][j];
-#pragma unroll 1
       for (int r = 0; r < 2; ++r) {
-        epilogue_layer16<G, CB, NT>(smem, t, a.scale[1 + 2 * r], a.shift[1 + 2 * r]);
         acc16_zero<NT>(acc);
         conv_segment16<G, CB, 3, 9, STAMPS>(ring, smem, acc);
         epilogue_layer16<G, CB, NT>(smem, acc, a.scale[2 + 2 * r], a.shift[2 + 2 * r]);
         acc16_zero<NT>(acc);
         conv_segment16<G, CB, 3, 9, STAMPS>(ring, smem, acc);
+        // t is fetched after the K loop: holding it across the 3x3 loop costs more (spills of
+        // the loaded values, i.e. the same exposed latency plus scratch traffic)
+        residual_addr16<G, CB, NT>(tr, CB, pos0, a.npos, 0);
+        residual_load16<NT>(tr, a.t);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) t[ct][j] += acc[ct][j];
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[ct][j][i] += (float)tr.rv[j][ct][i];
+        if (r == 0) epilogue_store16<false, NT>(acc, tr, a.t);
+        epilogue_layer16<G, CB, NT>(smem, acc, a.scale[3 + 2 * r], a.shift[3 + 2 * r]);
       }
-      epilogue_layer16<G, CB, NT>(smem, t, a.scale[5], a.shift[5]);
     }
     // ---- expand 1x1 (CB -> C) + residual, straight to HBM.  The residual of each output
     // pass is loaded before that pass's MFMAs (24 loads/lane); in pass 1 the 24 stores of

@@ -170,3 +170,43 @@ def test_eval_match_on_hip_engines(built, weight_files):
                              visits_per_move=16, leaves_per_round=4, max_moves=24, num_threads=4, seed=2)
     assert st.games == 8 and st.cur_wins + st.cand_wins + st.draws == 8
     assert st.visits >= 16 * (st.moves - 8) and st.positions > 0 and st.batches > 0
+
+
+@pytest.mark.gpu
+def test_edge_cases_empty_single_and_flags(built, weight_files):
+    """Empty run (no slot loaded) is a no-op, a batch of one works, RUN_ALL_SLOTS evaluates the
+    static batch like the TRT engine (trt_engine.cc:238-304), unsupported architectures and
+    versions fail at creation with a message, and ownership is served on request."""
+    from oracle import oracle
+    from p3achygo_amd import engine, features, netspec
+    name = "test_b3c256btl1"
+    pos = features.random_positions(3, seed=4, n_games=3)
+    _, raw = oracle.OracleNet(weight_files(name)).forward_features(pos, nthreads=4)
+    eng = engine.HipEngine(weight_files(name), 1)
+    eng.RunInference()                                   # nothing loaded
+    with pytest.raises(engine.EngineError):
+        eng.GetBatch(0)
+    eng.LoadBatch(0, pos[0:1])
+    eng.RunInference()
+    assert np.abs(np.ctypeslib.as_array(eng.GetBatch(0).move_logits) - raw[0][:362]).max() <= LOGIT_TOL
+    own = eng.GetOwnership(0)
+    assert np.abs(np.asarray(own) - np.tanh(raw[0][1526:1887])).max() <= 2e-2 or \
+        np.abs(np.asarray(own) - raw[0][1526:1887]).max() <= 2e-2
+    with pytest.raises(engine.EngineError):
+        eng.LoadBatch(1, pos[0:1])                       # slot out of range
+    eng.close()
+    eng = engine.HipEngine(weight_files(name), 4, flags=engine.FLAG_RUN_ALL_SLOTS)
+    eng.LoadBatch(2, pos[1:2])
+    eng.RunInference()
+    assert np.abs(np.ctypeslib.as_array(eng.GetBatch(2).move_logits) - raw[1][:362]).max() <= LOGIT_TOL
+    eng.GetBatch(0)                                      # every slot of the static batch was run
+    eng.close()
+    with pytest.raises(engine.EngineError):
+        engine.HipEngine(weight_files(name), 4, version=0)
+    import os
+    import tempfile
+    cfg = netspec.CONFIGS["tiny"]                        # C = 16: not a HIP-engine architecture
+    p = os.path.join(tempfile.mkdtemp(), "tiny.p3w")
+    netspec.save_p3w(p, cfg, netspec.generate_weights(cfg))
+    with pytest.raises(engine.EngineError, match="unsupported architecture"):
+        engine.HipEngine(p, 4)

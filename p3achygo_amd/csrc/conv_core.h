@@ -288,7 +288,9 @@ __device__ __forceinline__ void wait_lgkm_n(int n) {
 // lgkmcnt for exactly its own fragments (the 2+NT reads of the following step stay in
 // flight).  Body = U fully unrolled steps (U % 3 == 0 or the whole segment), runtime outer
 // loop; a new ring slot is acquired whenever the step being FETCHED enters a macro-step.
-template <class G, int COUT_PASS, int KW, int NTAPS_PAD, bool STAMPS = false, int NTn = 0>
+// SWAP: issue mfma(act fragment, weight fragment) instead, i.e. D[act row][weight row]: a lane
+// then holds 4 consecutive ACT rows for one weight row (k_bdense: rows are channels).
+template <class G, int COUT_PASS, int KW, int NTAPS_PAD, bool STAMPS = false, bool SWAP = false, int NTn = 0>
 __device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS)>& ring, char* smem,
                                              f32x16 (&acc)[2][NTn]) {
   using T = Tiling<G, COUT_PASS>;
@@ -355,7 +357,7 @@ __device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS)>& r
     } else {
       const int j = pc - 1;
       // chunk 2q+h of the slot: the k16 index q is static, so it is an immediate offset
-      switch (q) {
+      switch (q) {   // up to 24 k16 steps per tap (k_bdense: K = 384)
         case 0: fb[buf][j] = lds_read128<0>(b_base[j]); break;
         case 1: fb[buf][j] = lds_read128<32>(b_base[j]); break;
         case 2: fb[buf][j] = lds_read128<64>(b_base[j]); break;
@@ -363,7 +365,23 @@ __device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS)>& r
         case 4: fb[buf][j] = lds_read128<128>(b_base[j]); break;
         case 5: fb[buf][j] = lds_read128<160>(b_base[j]); break;
         case 6: fb[buf][j] = lds_read128<192>(b_base[j]); break;
-        default: fb[buf][j] = lds_read128<224>(b_base[j]); break;
+        case 7: fb[buf][j] = lds_read128<224>(b_base[j]); break;
+        case 8: fb[buf][j] = lds_read128<256>(b_base[j]); break;
+        case 9: fb[buf][j] = lds_read128<288>(b_base[j]); break;
+        case 10: fb[buf][j] = lds_read128<320>(b_base[j]); break;
+        case 11: fb[buf][j] = lds_read128<352>(b_base[j]); break;
+        case 12: fb[buf][j] = lds_read128<384>(b_base[j]); break;
+        case 13: fb[buf][j] = lds_read128<416>(b_base[j]); break;
+        case 14: fb[buf][j] = lds_read128<448>(b_base[j]); break;
+        case 15: fb[buf][j] = lds_read128<480>(b_base[j]); break;
+        case 16: fb[buf][j] = lds_read128<512>(b_base[j]); break;
+        case 17: fb[buf][j] = lds_read128<544>(b_base[j]); break;
+        case 18: fb[buf][j] = lds_read128<576>(b_base[j]); break;
+        case 19: fb[buf][j] = lds_read128<608>(b_base[j]); break;
+        case 20: fb[buf][j] = lds_read128<640>(b_base[j]); break;
+        case 21: fb[buf][j] = lds_read128<672>(b_base[j]); break;
+        case 22: fb[buf][j] = lds_read128<704>(b_base[j]); break;
+        default: fb[buf][j] = lds_read128<736>(b_base[j]); break;
       }
     }
   };
@@ -387,7 +405,8 @@ __device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS)>& r
 #pragma unroll
       for (int m = 0; m < 2 * T::NT; ++m) {
         const int mt = m / T::NT, j = m % T::NT;
-        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u % 3][mt], fb[u % 3][j], acc[mt][j], 0, 0, 0);
+        acc[mt][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[u % 3][j], fa[u % 3][mt], acc[mt][j], 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u % 3][mt], fb[u % 3][j], acc[mt][j], 0, 0, 0);
         if (m < 1 + T::NT) {
           __builtin_amdgcn_sched_barrier(0);
           if (do_fetch) fetch_piece(o, u + 2, m);

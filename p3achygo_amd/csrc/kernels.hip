@@ -415,6 +415,12 @@ __global__ void __launch_bounds__(kWG, 2) k_lconv(LConvArgs a) {
 // =======================================================================================
 constexpr int kTtStride = 784;  // bytes per channel row in LDS: 384 fp16 + 16 B pad
 
+// Tt seen as a conv act buffer: one slot per channel (128 per pass), K = 384 board points.
+struct GeoTt {
+  static constexpr int NPOS = 1, CB = 384, NCH = 48, SLOTB = kTtStride, PAD = 0, S = 1, NROWS = 128,
+                       NT_POS = 4, PADTOP = 0, PSLOTS = 128, ACT_BYTES = 128 * kTtStride, NT_TOTAL = 4;
+};
+
 template <int C>
 __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -470,25 +476,15 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
       }
 #pragma unroll 1
       for (int jp = 0; jp < 3; ++jp) {
-        f32x16 acc[2];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
-        const uint32_t b_off = (uint32_t)((h * 128 + jg * 64 + lr) * 16);
-        const uint32_t a_base = (uint32_t)((ct * 32 + lr) * kTtStride + h * 16);
-        uint32_t wslot = 0;
-#pragma unroll 4
-        for (int q = 0; q < NQ; ++q) {
-          if ((q & 3) == 0) wslot = ring_acquire(ring, smem);
-          const uint32_t wk = wslot + (q & 3) * 4096;
-          const h8 av = *(const h8*)(smem + a_base + q * 32);
-          const h8 b0 = *(const h8*)(smem + wk + b_off);
-          const h8 b1 = *(const h8*)(smem + wk + b_off + 512);
-          if (ct_active) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
-          }
-        }
+        // D[c][j] = sum_i Tt[c][i] * W[i][j]: the conv K loop with its operands swapped —
+        // "act buffer" = Tt (slot = channel, 48 chunks of 8 board points), "weights" = the
+        // 128 dense columns of this pass streamed through the ring; fragments are prefetched
+        // two k16 steps ahead exactly as in the conv kernels.
+        f32x16 acc2[2][1];
+        acc_zero<GeoTt, 128>(acc2);
+        conv_segment<GeoTt, 128, 1, 1, false, true>(ring, smem, acc2);
         if (!ct_active) continue;
+        const f32x16 acc[2] = {acc2[0][0], acc2[1][0]};
         // epilogue: rows = channel (regs), cols = j (lanes)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {

@@ -386,7 +386,7 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
       c0.in = e->d_x; c0.out16 = e->d_t; c0.npos = npos;
       c0.wstream = e->d_arena + bp.stream_off; c0.nms_total = bp.nms;
       c0.scale = e->dev<float>(bp.bn[0].scale_off); c0.shift = e->dev<float>(bp.bn[0].shift_off);
-      if (!e->check(p3::launch_conv1x1(C, 0, c0, grid_for(e, npos, npw), s), "launch conv_first")) return false;
+      if (!e->check(p3::launch_conv1x1(C, 0, c0, e->n_cu, s), "launch conv_first")) return false;
       p3::BDenseArgs d{};
       d.t = e->d_t; d.u = e->d_u; d.npos = npos;
       d.wstream = e->d_arena + bp.stream2_off; d.nms_total = bp.nms2;
@@ -396,7 +396,7 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
       p3::Conv1x1Args c1{};
       c1.in = e->d_u; c1.out16 = e->d_x; c1.npos = npos;
       c1.wstream = e->d_arena + bp.stream3_off; c1.nms_total = bp.nms3;
-      if (!e->check(p3::launch_conv1x1(C, 1, c1, grid_for(e, npos, npw), s), "launch conv_last")) return false;
+      if (!e->check(p3::launch_conv1x1(C, 1, c1, e->n_cu, s), "launch conv_last")) return false;
     } else if (bp.kind == 4) {
       _Float16* bufs[3] = {e->d_x, e->d_t, e->d_u};
       for (const LayerPlan& lp : bp.layers) {
@@ -406,7 +406,7 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
         a.pre = lp.pre_bn >= 0; a.act = lp.act_bn >= 0; a.res = lp.res;
         if (a.pre) { a.scale_in = e->dev<float>(bp.bn[lp.pre_bn].scale_off); a.shift_in = e->dev<float>(bp.bn[lp.pre_bn].shift_off); }
         if (a.act) { a.scale_out = e->dev<float>(bp.bn[lp.act_bn].scale_off); a.shift_out = e->dev<float>(bp.bn[lp.act_bn].shift_off); }
-        if (!e->check(p3::launch_lconv(lp.kw, lp.cin, lp.cout, a, grid_for(e, npos, 2), s), "launch k_lconv")) return false;
+        if (!e->check(p3::launch_lconv(lp.kw, lp.cin, lp.cout, a, e->n_cu, s), "launch k_lconv")) return false;
       }
     } else {
       p3::BlockArgs a = block_args(e, bp, npos);
@@ -420,7 +420,7 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
     p3::Conv1x1Args c{};
     c.in = e->d_x; c.out32 = e->d_hp; c.npos = npos;
     c.wstream = e->d_arena + e->heads_stream_off; c.nms_total = e->heads_nms;
-    if (!e->check(p3::launch_conv1x1(C, 2, c, grid_for(e, npos, npw), s), "launch head convs")) return false;
+    if (!e->check(p3::launch_conv1x1(C, 2, c, e->n_cu, s), "launch head convs")) return false;
     p3::HeadsArgs h{};
     h.hp = e->d_hp; h.out = e->d_out; h.npos = npos; h.V = wf.V;
     auto F = [&](const char* n) { return e->dev<float>(e->head_off.at(n)); };

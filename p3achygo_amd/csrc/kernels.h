@@ -106,10 +106,10 @@ hipError_t launch_block_stamps(const BlockArgs& a, int grid, hipStream_t s);
 hipError_t launch_init(int C, const InitArgs& a, int grid, hipStream_t s);
 // which: 0 = broadcast conv_first (bn+mish prologue, mish epilogue), 1 = broadcast
 // conv_last (+residual), 2 = head convs (fp32 out, COUT = 96)
-hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipStream_t s);
+hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int n_cu, hipStream_t s);   // picks its own grid
 hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s);
 // layer-wise conv: (kw, cin, cout) in {(1,384,192), (3,192,192), (1,192,384)}; two positions per workgroup
-hipError_t launch_lconv(int kw, int cin, int cout, const LConvArgs& a, int grid, hipStream_t s);
+hipError_t launch_lconv(int kw, int cin, int cout, const LConvArgs& a, int n_cu, hipStream_t s);
 hipError_t launch_heads(const HeadsArgs& a, int grid, hipStream_t s);
 const char* block_kernel_name(int C, int kind, int L);
 

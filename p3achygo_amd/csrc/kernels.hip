@@ -268,24 +268,32 @@ __global__ void __launch_bounds__(kWG, 2) k_conv1x1(Conv1x1Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr uint32_t kRingOff = G::ACT_BYTES;
   act_zero<G>(smem);
+  // Output passes are split ACROSS workgroups: workgroup b owns pass cp = (b / 8) % NCP of the
+  // position groups pg0, pg0 + gridDim/NCP, ...  The NCP workgroups of one position group are
+  // 8 block ids apart, i.e. on the same XCD and dispatched together, so the input slices they
+  // all stage come from HBM once and from that XCD's L2 afterwards (each workgroup restaging
+  // every pass itself re-read them from HBM: the working set of an XCD's 32 workgroups is
+  // larger than its L2).  gridDim.x is a multiple of 8 * NCP (conv_split_grid).
+  const int cp = (blockIdx.x >> 3) % NCP;
+  const int pg0 = (blockIdx.x / (8 * NCP)) * 8 + (blockIdx.x & 7);
+  const int pg_stride = gridDim.x / NCP;
   Ring<T::RS> ring;
-  ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
+  ring_init(ring, smem, (const char*)a.wstream + (size_t)cp * (a.nms_total / NCP) * T::RS, a.nms_total / NCP, kRingOff);
   lds_barrier();
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lg = wid / T::CG;
   const int lr = lane & 31;
 
-  // Staging is software-pipelined: the slice after the current one (next K slice, next output
-  // pass or next position) is fetched into registers while the current segment's MFMAs run,
-  // its BN+mish is applied in registers before the barrier that frees the act buffer.
+  // Staging is software-pipelined: the slice after the current one (next K slice or next
+  // position) is fetched into registers while the current segment's MFMAs run, its BN+mish
+  // is applied in registers before the barrier that frees the act buffer.
   constexpr int NIP = CIN / CB;
   XRegs<G> xr;
-  stage_load<G>(xr, a.in, CIN, blockIdx.x * NPOS, a.npos, 0);
+  stage_load<G>(xr, a.in, CIN, pg0 * NPOS, a.npos, 0);
   int pending_stores = 0;   // vector-memory ops of the previous epilogue that may still be in flight
-  for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS) {
-#pragma unroll 1
-    for (int cp = 0; cp < NCP; ++cp) {
+  for (int pos0 = pg0 * NPOS; pos0 < a.npos; pos0 += pg_stride * NPOS) {
+    {
       f32x16 acc[2][T::NT];
       acc_zero<G, CP>(acc);
 #pragma unroll 1
@@ -296,7 +304,7 @@ __global__ void __launch_bounds__(kWG, 2) k_conv1x1(Conv1x1Args a) {
         int nip = ip + 1, npos0 = pos0;
         if (nip == NIP) {
           nip = 0;
-          if (cp + 1 == NCP) npos0 = pos0 + gridDim.x * NPOS;   // past the end: clamped to a valid position
+          npos0 = pos0 + pg_stride * NPOS;   // past the end: clamped to a valid position
         }
         stage_load<G>(xr, a.in, CIN, npos0, a.npos, nip * G::NCH);
         ring_note_inflight(ring, pending_stores + kXLoads);
@@ -357,16 +365,19 @@ __global__ void __launch_bounds__(kWG, 2) k_lconv(LConvArgs a) {
   using T = Tiling<G, CP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   act_zero<G>(smem);
-  Ring<T::RS> ring;
-  ring_init(ring, smem, a.wstream, a.nms_total, G::ACT_BYTES);
-  lds_barrier();
   constexpr int NIP = CIN / CB, NCP = COUT / CP;
+  // output passes split across workgroups, as in k_conv1x1
+  const int cp = (blockIdx.x >> 3) % NCP;
+  const int pg0 = (blockIdx.x / (8 * NCP)) * 8 + (blockIdx.x & 7);
+  const int pg_stride = gridDim.x / NCP;
+  Ring<T::RS> ring;
+  ring_init(ring, smem, (const char*)a.wstream + (size_t)cp * (a.nms_total / NCP) * T::RS, a.nms_total / NCP, G::ACT_BYTES);
+  lds_barrier();
   XRegs<G> xr;   // software-pipelined staging, as in k_conv1x1
-  stage_load<G>(xr, a.in, CIN, blockIdx.x * NPOS, a.npos, 0);
+  stage_load<G>(xr, a.in, CIN, pg0 * NPOS, a.npos, 0);
   int pending_stores = 0;
-  for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS) {
-#pragma unroll 1
-    for (int cp = 0; cp < NCP; ++cp) {
+  for (int pos0 = pg0 * NPOS; pos0 < a.npos; pos0 += pg_stride * NPOS) {
+    {
       f32x16 acc[2][T::NT];
       acc_zero<G, CP>(acc);
 #pragma unroll 1
@@ -377,7 +388,7 @@ __global__ void __launch_bounds__(kWG, 2) k_lconv(LConvArgs a) {
         int nip = ip + 1, npos0 = pos0;
         if (nip == NIP) {
           nip = 0;
-          if (cp + 1 == NCP) npos0 = pos0 + gridDim.x * NPOS;
+          npos0 = pos0 + pg_stride * NPOS;
         }
         stage_load<G>(xr, a.in, CIN, npos0, a.npos, nip * G::NCH);
         ring_note_inflight(ring, pending_stores + kXLoads);
@@ -860,11 +871,23 @@ hipError_t launch_init(int C, const InitArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Grid of the kernels that split their NCP output passes across workgroups: a multiple of
+// 8 * NCP, at most n_cu, enough for every (position group, pass) pair.
+static int conv_split_grid(int npos, int npos_per_wg, int ncp, int n_cu) {
+  const int unit = 8 * ncp;
+  const int groups = (npos + npos_per_wg - 1) / npos_per_wg;
+  int want = ((groups + 7) / 8) * unit;                 // pairs, padded to whole units
+  int cap = (n_cu / unit) * unit;
+  if (cap < unit) cap = unit;
+  return want < cap ? want : cap;
+}
+
 template <int CIN, int COUT, bool PRE, int EPI>
-static hipError_t launch_conv1x1_t(const Conv1x1Args& a, int grid, hipStream_t s) {
+static hipError_t launch_conv1x1_t(const Conv1x1Args& a, int n_cu, hipStream_t s) {
   constexpr int CB = CIN >= 256 ? 128 : 64;
   using G = Geo<128 / CB, CB, 1>;
   constexpr int CP = (COUT >= 128 && CB == 128) ? 128 : 64;
+  const int grid = conv_split_grid(a.npos, 128 / CB, (COUT + CP - 1) / CP, n_cu);
   constexpr size_t lds = G::ACT_BYTES + ring_bytes(CP);
   static bool attr_set = false;
   if (!attr_set) {
@@ -876,7 +899,7 @@ static hipError_t launch_conv1x1_t(const Conv1x1Args& a, int grid, hipStream_t s
   return hipGetLastError();
 }
 
-hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipStream_t s) {
+hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipStream_t s) {   // grid = CU count
   if (C == 192) {
     if (which == 0) return launch_conv1x1_t<192, 192, true, 0>(a, grid, s);
     if (which == 1) return launch_conv1x1_t<192, 192, false, 1>(a, grid, s);
@@ -898,8 +921,9 @@ hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipS
 }
 
 template <int KW, int CIN, int COUT, bool PRE, bool ACT, bool RES>
-static hipError_t launch_lconv_t(const LConvArgs& a, int grid, hipStream_t s) {
+static hipError_t launch_lconv_t(const LConvArgs& a, int n_cu, hipStream_t s) {
   using G = Geo<2, 64, KW>;
+  const int grid = conv_split_grid(a.npos, 2, COUT / 64, n_cu);
   constexpr size_t lds = G::ACT_BYTES + ring_bytes(64);
   static bool attr_set = false;
   if (!attr_set) {
@@ -912,7 +936,7 @@ static hipError_t launch_lconv_t(const LConvArgs& a, int grid, hipStream_t s) {
 }
 
 // the seven layer shapes of C=384 / C_b=192 btl and nbt blocks (engine.cpp build_plan)
-hipError_t launch_lconv(int kw, int cin, int cout, const LConvArgs& a, int grid, hipStream_t s) {
+hipError_t launch_lconv(int kw, int cin, int cout, const LConvArgs& a, int grid, hipStream_t s) {   // grid = CU count
   const int f = (a.pre ? 4 : 0) | (a.act ? 2 : 0) | (a.res ? 1 : 0);
   if (kw == 1 && cin == 384 && cout == 192) {
     if (f == 6) return launch_lconv_t<1, 384, 192, true, true, false>(a, grid, s);    // btl reduce

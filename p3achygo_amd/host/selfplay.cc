@@ -110,30 +110,73 @@ struct HipEvaluator final : Evaluator {
 class GameRecorder {
  public:
   GameRecorder(const std::string& path, int gen, const std::string& worker_id, int flush_interval)
-      : sgf_(path + "/sgf", gen, worker_id), tf_(path + "/chunks", gen, worker_id), flush_interval_(flush_interval) {}
+      : sgf_(path + "/sgf", gen, worker_id), tf_(path + "/chunks", gen, worker_id), flush_interval_(flush_interval) {
+    io_ = std::thread([this] { IoLoop(); });   // game_recorder.cc:83: flushes run on an IO thread
+  }
+  ~GameRecorder() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    io_.join();
+  }
   void RecordGame(const Board& init_board, const Game& game, std::vector<MoveSearchRecord> infos) {
     if (init_board.IsEmpty()) sgf_.RecordGame(SgfGameString(game, "p3achygo", "p3achygo"));   // game_recorder.cc:20,101-108
     std::lock_guard<std::mutex> l(mu_);
     tf_.RecordGame(init_board, game, std::move(infos));
-    ++buffered_;
+    if (++buffered_ >= flush_interval_ && !flushing_) {   // should_flush_, game_recorder.cc:113-115
+      want_flush_ = true;
+      cv_.notify_all();
+    }
   }
-  bool ShouldFlush() {
-    std::lock_guard<std::mutex> l(mu_);
-    return buffered_ >= flush_interval_;
-  }
+  // Final flush (the reference flushes on exit): waits for the IO thread, then writes the rest.
   void Flush() {
-    sgf_.Flush();
-    std::lock_guard<std::mutex> l(mu_);
-    examples_ += tf_.Flush();
+    std::unique_lock<std::mutex> l(mu_);
+    cv_.wait(l, [this] { return !flushing_ && !want_flush_; });
+    auto recs = tf_.TakeRecords();
     buffered_ = 0;
+    l.unlock();
+    sgf_.Flush();
+    const int n = tf_.FlushRecords(std::move(recs));
+    l.lock();
+    examples_ += n;
   }
-  long examples() const { return examples_; }
+  long examples() {
+    std::lock_guard<std::mutex> l(mu_);
+    return examples_;
+  }
 
  private:
+  // Unlike the reference (which holds every game thread's mutex while it replays the games,
+  // game_recorder.cc:158-175) the buffered games are detached under the lock and written
+  // outside it: no game waits for a flush.
+  void IoLoop() {
+    std::unique_lock<std::mutex> l(mu_);
+    for (;;) {
+      cv_.wait(l, [this] { return want_flush_ || quit_; });
+      if (quit_) return;
+      want_flush_ = false;
+      flushing_ = true;
+      auto recs = tf_.TakeRecords();
+      buffered_ = 0;
+      l.unlock();
+      sgf_.Flush();
+      const int n = tf_.FlushRecords(std::move(recs));
+      l.lock();
+      examples_ += n;
+      flushing_ = false;
+      cv_.notify_all();
+    }
+  }
+
   SgfRecorder sgf_;
   TfRecorder tf_;
   std::mutex mu_;
+  std::condition_variable cv_;
+  std::thread io_;
   int flush_interval_, buffered_ = 0;
+  bool want_flush_ = false, flushing_ = false, quit_ = false;
   long examples_ = 0;
 };
 
@@ -768,7 +811,6 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
       request_run(h);
     }
     if (rc) break;
-    if (recorder && recorder->ShouldFlush()) recorder->Flush();
     ++iter;
     if (!measuring && iter >= warmup_batches) {
       totals(base);

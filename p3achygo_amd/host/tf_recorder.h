@@ -226,13 +226,23 @@ class TfRecorder {
   int batch_num() const { return batch_; }
   const std::string& last_chunk() const { return last_chunk_; }
 
+  struct Record {
+    Board init_board;
+    Game game;
+    std::vector<MoveSearchRecord> infos;
+  };
+  // Detaches the buffered games (cheap; call under the caller's lock), to be written with
+  // FlushRecords outside it: the replay of every game is the expensive part.
+  std::vector<Record> TakeRecords() { return std::move(records_); }
+  int Flush() { return FlushRecords(TakeRecords()); }
+
   // tf_recorder.cc:113-467.  Returns the number of examples written (0: no file).
-  int Flush() {
+  int FlushRecords(std::vector<Record> records) {
     size_t trainable_visits = 0, fast_visits = 0, n_trainable = 0, n_fast = 0;
     std::vector<std::string> examples;
     std::vector<MoveSearchStats> all_stats;
     std::vector<float> all_weights;
-    for (Record& rec : records_) {
+    for (Record& rec : records) {
       const Game& game = rec.game;
       const std::vector<MoveSearchRecord>& infos = rec.infos;
       size_t num_trainable = 0;
@@ -292,8 +302,8 @@ class TfRecorder {
         }
       }
     }
-    const int num_games = (int)records_.size();
-    records_.clear();
+    const int num_games = (int)records.size();
+    records.clear();
     if (examples.empty()) return 0;
 
     const int num_records = (int)examples.size();
@@ -328,12 +338,6 @@ class TfRecorder {
   static int16_t EncodeLoc16(Loc l) { return (int16_t)(l.i * kBoardLen + l.j); }   // Loc -> int16, loc.h:24-26
 
  private:
-  struct Record {
-    Board init_board;
-    Game game;
-    std::vector<MoveSearchRecord> infos;
-  };
-
   // percentile table + expected_std bins + sel_mult_mean, tf_recorder.cc:318-460
   static void WriteStats(const std::string& path, const std::vector<MoveSearchStats>& stats,
                          const std::vector<float>& weights) {

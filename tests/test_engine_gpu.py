@@ -210,3 +210,39 @@ def test_edge_cases_empty_single_and_flags(built, weight_files):
     netspec.save_p3w(p, cfg, netspec.generate_weights(cfg))
     with pytest.raises(engine.EngineError, match="unsupported architecture"):
         engine.HipEngine(p, 4)
+
+
+@pytest.mark.gpu
+def test_repeated_and_concurrent_runs_are_bit_identical(built, weight_files):
+    """Race screen for the hand-synchronised kernels (counted vmcnt / lgkmcnt, raw barriers): the
+    same batch gives bit-identical raw outputs on every run, also while a second engine instance
+    runs on the same device from another thread (how the self-play host drives it)."""
+    import hashlib
+    from p3achygo_amd import engine, features
+    name = "b12c256btl3"
+    batch = 512
+    pos = np.tile(features.random_positions(64, seed=2, n_games=16), batch // 64).copy()
+
+    def digest(eng):
+        h = hashlib.sha1()
+        for s in (0, 1, batch // 2, batch - 1, 77):
+            h.update(eng.get_raw(s).tobytes())
+        return h.hexdigest()
+
+    def worker(out, iters):
+        eng = engine.HipEngine(weight_files(name), batch)
+        ds = set()
+        for _ in range(iters):
+            eng.load_all(pos)
+            eng.RunInference()
+            ds.add(digest(eng))
+        eng.close()
+        out.append(ds)
+
+    solo = []
+    worker(solo, 20)
+    assert len(solo[0]) == 1
+    outs = []
+    ths = [threading.Thread(target=worker, args=(outs, 20)) for _ in range(2)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert len(outs) == 2 and outs[0] == outs[1] == solo[0]

@@ -291,7 +291,15 @@ float p3host_t_quantile(int dof) { return CachedTQuantile(dof); }
 // out: [0] visits [1] aborted [2] collisions [3] rounds [4] root n [5] move index (-1 noop)
 //      [6] sum of root child visits [7] nodes whose n != 1 + sum(child visits) (must be 0)
 //      [8] nodes left with n_in_flight != 0 (must be 0) [9] evaluations requested
+int p3host_test_batch_search_ex(int batch, int budget, int mode, int q_fn, int n_fn, int collision, int detector,
+                                int* out);
 int p3host_test_batch_search(int batch, int budget, int* out) {
+  return p3host_test_batch_search_ex(batch, budget, /*batch mode*/ 1, 0, 0, 0, 0, out);
+}
+// mode: 0 concurrent rounds, 1 batch; q_fn 0/1/2 identity / virtual loss / soft; n_fn 0/1 identity /
+// virtual visit; collision 0/1/2 abort / retry / smart retry; detector 0..3 noop / n-in-flight / level / product
+int p3host_test_batch_search_ex(int batch, int budget, int mode, int q_fn, int n_fn, int collision, int detector,
+                                int* out) {
   Game game(7.5f, true);
   NodePool pool;
   TreeNode* root = pool.Create();
@@ -307,6 +315,10 @@ int p3host_test_batch_search(int batch, int budget, int* out) {
   ParallelSearchParams p;
   p.batch = batch;
   p.visit_budget = budget;
+  p.mode = (SearchMode)mode;
+  p.fns = VirtualFns{(QFn)q_fn, (NFn)n_fn, -1.5f};
+  p.collision = (CollisionPolicy)collision;
+  p.detector = (CollisionDetector)detector;
   BatchSearch s;
   s.Begin(&game, &pool, root, kBlack, p);
   int evals = 0;

@@ -29,6 +29,14 @@ struct EvalPlayerConfig {   // PlayerSearchConfig (player_config.h:20-108)
   float c_puct = 1.0f, c_puct_visit_scaling = 0.45f, root_fpu = 0.2f;
   bool var_scale_cpuct = false;
   int var_scale_prior_visits = 0;
+  // parallel-search knobs, defaults of player_config.h:76-108
+  SearchMode search_mode = SearchMode::kConcurrent;
+  QFn q_fn = QFn::kVirtualLossSoft;
+  NFn n_fn = NFn::kVirtualVisit;
+  float vl_delta = -1.5f;
+  CollisionPolicy collision_policy = CollisionPolicy::kAbort;
+  CollisionDetector collision_detector = CollisionDetector::kNoOp;
+  int max_collision_retries = 4;
 };
 
 class EvalGame {
@@ -91,6 +99,11 @@ class EvalGame {
     p.puct.root_fpu = cfg_[side].root_fpu;
     p.puct.enable_var_scaling = cfg_[side].var_scale_cpuct;
     p.puct.var_scale_prior_visits = cfg_[side].var_scale_prior_visits;
+    p.mode = cfg_[side].search_mode;
+    p.fns = VirtualFns{cfg_[side].q_fn, cfg_[side].n_fn, cfg_[side].vl_delta};
+    p.collision = cfg_[side].collision_policy;
+    p.detector = cfg_[side].collision_detector;
+    p.max_collision_retries = cfg_[side].max_collision_retries;
     parallel_ = cfg_[side].num_threads_per_game > 1;   // UsesParallelSearch, eval.cc:99-101
     if (parallel_) {
       search_.Begin(&game_, &pool_[side], tree_[side], color_, p);

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <limits>
 #include <unordered_set>
 #include <vector>
 
@@ -26,15 +27,31 @@
 namespace p3 {
 
 
-// ---- PUCT scores, top-4 (search_policy.h:159-351, IdentityQ / IdentityN) ---------------------
-inline void PuctScoresAll(const TreeNode* node, const PuctParams& pp, bool is_root, float* scores) {
+// ---- PUCT scores, top-4 (search_policy.h:159-351) with the virtual-loss Q / N functions ----------
+enum class QFn : uint8_t { kIdentity = 0, kVirtualLoss = 1, kVirtualLossSoft = 2 };   // search_policy.h:400-446
+enum class NFn : uint8_t { kIdentity = 0, kVirtualVisit = 1 };                          // :406-459
+struct VirtualFns {
+  QFn q = QFn::kIdentity;
+  NFn n = NFn::kIdentity;
+  float vl_delta = -1.5f;
+  float Q(float q_, int n_, int in_flight) const {
+    if (q == QFn::kVirtualLoss) return q_ + in_flight * vl_delta;
+    if (q == QFn::kVirtualLossSoft) return in_flight == 0 ? q_ : (q_ * n_ + in_flight * vl_delta) / (float)(n_ + in_flight);
+    return q_;
+  }
+  float N(int n_, int in_flight) const { return n == NFn::kVirtualVisit ? (float)(n_ + in_flight) : (float)n_; }
+};
+
+inline void PuctScoresAll(const TreeNode* node, const PuctParams& pp, bool is_root, float* scores,
+                          const VirtualFns& vf = VirtualFns{}) {
   const int n = node->n;
   const float v = node->v;
-  int cv[kNumMoves] = {};
+  int cv[kNumMoves] = {}, inflight[kNumMoves] = {};
   float qs[kNumMoves], qvars[kNumMoves];
   float q_std_weighted = 0;
   for (const ChildEdge& e : node->children) {
     cv[e.action] = e.visits;
+    if (e.node) inflight[e.action] = e.node->n_in_flight;
     if (e.visits > 0) qs[e.action] = -e.node->v;
     if (e.visits >= 3) {
       qvars[e.action] = e.node->v_var;
@@ -44,11 +61,11 @@ inline void PuctScoresAll(const TreeNode* node, const PuctParams& pp, bool is_ro
   const float q_std_mean = q_std_weighted / n;
   float p_explored = 0;
   for (const ChildEdge& e : node->children)
-    if (e.visits > 0) p_explored += node->move_probs[e.action];
+    if (e.visits + inflight[e.action] > 0) p_explored += node->move_probs[e.action];
   const float v_fpu = v - (is_root ? pp.root_fpu : kDefaultFPU) * std::sqrt(p_explored);
   const float c_puct = pp.c_puct + pp.c_puct_visit_scaling * std::log((n + 500.0f) / 500.0f);
   float total_n = 1;
-  for (const ChildEdge& e : node->children) total_n += e.visits;
+  for (const ChildEdge& e : node->children) total_n += vf.N(e.visits, inflight[e.action]);
   const float sqrt_n = std::sqrt(total_n);
   for (int a = 0; a < kNumMoves; ++a) {
     float scale = 1.0f;
@@ -56,15 +73,17 @@ inline void PuctScoresAll(const TreeNode* node, const PuctParams& pp, bool is_ro
       const float pw = (float)pp.var_scale_prior_visits;
       scale = (pw + cv[a] * (std::sqrt(qvars[a]) / q_std_mean)) / (pw + cv[a]);
     }
-    scores[a] = c_puct * scale * node->move_probs[a] * (sqrt_n / (1 + cv[a])) + (cv[a] > 0 ? qs[a] : v_fpu);
+    const float child_n = vf.N(cv[a], inflight[a]);
+    const float q = vf.Q(cv[a] > 0 ? qs[a] : v_fpu, cv[a], inflight[a]);
+    scores[a] = c_puct * scale * node->move_probs[a] * (sqrt_n / (1 + child_n)) + q;
   }
 }
 
 using TopActions = std::array<std::pair<int, float>, 4>;   // (action or -1, score)
 inline TopActions PuctTopScores(const TreeNode* node, const Board& board, Color color, const PuctParams& pp,
-                                bool is_root) {   // search_policy.h:318-351
+                                bool is_root, const VirtualFns& vf = VirtualFns{}) {   // search_policy.h:318-351
   float scores[kNumMoves];
-  PuctScoresAll(node, pp, is_root, scores);
+  PuctScoresAll(node, pp, is_root, scores, vf);
   TopActions top;
   top.fill({-1, -1e6f});
   for (int a = 0; a < kNumMoves; ++a) {
@@ -110,10 +129,24 @@ inline void RecomputeNodeStats(TreeNode* node) {
   node->v_err = w_err / node->n;
 }
 
-struct ParallelSearchParams {   // Search::Params (search.h:92-107), batch mode
-  int batch = 8;                // num_threads: leaves per round
+enum class SearchMode : uint8_t { kConcurrent = 0, kBatch = 1 };                           // Search::Mode
+enum class CollisionPolicy : uint8_t { kAbort = 0, kRetry = 1, kSmartRetry = 2 };          // search.h:28-32
+enum class CollisionDetector : uint8_t { kNoOp = 0, kNInFlight = 1, kLevelSaturation = 2, kProduct = 3 };   // :34-39
+
+struct ParallelSearchParams {   // Search::Params (search.h:92-107)
+  int batch = 8;                // num_threads: descents (leaves) per round
   int visit_budget = 128;       // total_visit_budget
   PuctParams puct;
+  // kBatch: priority-first forks with identity Q / N (BatchSearch, search.cc:487-640, which
+  // "currently ignores policies").  kConcurrent: the round structure of SearchTask
+  // (search.cc:336-458) — every worker descends through the marks (n_in_flight) the earlier
+  // workers of the round left, with the Q / N functions, collision policy and detector below;
+  // the reference runs the workers on threads, here they descend one after the other.
+  SearchMode mode = SearchMode::kBatch;
+  VirtualFns fns;               // q_fn_kind / n_fn_kind / vl_delta
+  CollisionPolicy collision = CollisionPolicy::kAbort;
+  int max_collision_retries = 4;
+  CollisionDetector detector = CollisionDetector::kNoOp;
 };
 struct ParallelSearchResult {   // Search::Result
   Loc move = kPassLoc;
@@ -131,6 +164,7 @@ class BatchSearch {
     workers_.assign(p_.batch, Worker{});
     pending_.resize(p_.batch);
     n_evals_ = 0;
+    stalled_rounds_ = 0;
     state_ = game->IsGameOver() ? State::kDone : (root->evaluated ? State::kRound : State::kRootEval);
   }
 
@@ -157,10 +191,17 @@ class BatchSearch {
           state_ = State::kRoundWait;
           if (n_evals_ > 0) return n_evals_;
           break;
-        case State::kRoundWait:
+        case State::kRoundWait: {
+          const int before = res_.num_visits;
           FetchAndBackup();
+          // Guard (not in the reference, which would spin): a detector that fires on every
+          // descent (n-in-flight with fewer than four workers: threshold log2(batch) = 1) leaves
+          // rounds without a single completed visit; give up after 32 of them in a row.
+          stalled_rounds_ = res_.num_visits == before ? stalled_rounds_ + 1 : 0;
+          if (stalled_rounds_ >= 32) { Finish(); return 0; }
           state_ = State::kRound;
           break;
+        }
       }
     }
   }
@@ -181,8 +222,22 @@ class BatchSearch {
   };
   struct Fork { float diff; int path_num, path_index, puct_index; };
 
-  // Descend (search.cc:84-245) for one worker; false on collision (the path is undone).
+  bool DetectorFires(int in_flight_old, int level) const {   // search.h:447-485
+    const int base = std::max(1, (int)std::log2((double)std::max(p_.batch, 1)));   // RunWithDetector
+    const bool nf = in_flight_old + 1 >= base;
+    const bool lv = level >= 0 && level < 8 && pending_level_[level] >= base * (level + 1);
+    switch (p_.detector) {
+      case CollisionDetector::kNInFlight: return nf;
+      case CollisionDetector::kLevelSaturation: return lv;
+      case CollisionDetector::kProduct: return nf && lv;
+      default: return false;
+    }
+  }
+
+  // Descend (search.cc:84-245) for one worker; false on collision (the marks are undone, the
+  // colliding path stays in w.path for the collision policy).
   bool Descend(Worker& w, const std::vector<PathElem>& prefix) {
+    const VirtualFns fns = p_.mode == SearchMode::kConcurrent ? p_.fns : VirtualFns{};
     w.pos = root_pos_;
     w.path.clear();
     Color c = color_;
@@ -200,7 +255,7 @@ class BatchSearch {
       int action;
       TopActions top;
       if (idx < prefix.size()) { action = prefix[idx].action; top = prefix[idx].top; }
-      else { top = PuctTopScores(cur, w.pos.board, c, p_.puct, cur == root_); action = top[0].first; }
+      else { top = PuctTopScores(cur, w.pos.board, c, p_.puct, cur == root_, fns); action = top[0].first; }
       if (action < 0) action = kPassEncoding;   // no legal scored move: pass is always legal
       w.pos.PlayMove(MoveLoc(action), c);
       c = Opp(c);
@@ -218,6 +273,10 @@ class BatchSearch {
         cur = child;   // a new node: claimed by this descent
         break;
       }
+      if (p_.mode == SearchMode::kConcurrent && DetectorFires(child_in_flight, (int)w.path.size() + 1)) {
+        w.path.push_back({child, -1, {}});
+        return collide();
+      }
       cur = child;
       if (w.pos.IsGameOver() || child->is_terminal) {
         if (child_in_flight == 0) break;      // this descent claims the terminal node
@@ -226,17 +285,83 @@ class BatchSearch {
       }
     }
     w.path.push_back({cur, -1, {}});
+    {
+      const int level = (int)w.path.size() - 2;   // inc_pending_at_level, search.cc:212
+      if (level >= 0 && level < 8) ++pending_level_[level];
+    }
     if (w.pos.IsGameOver()) cur->is_terminal = true;
     w.needs_eval = !cur->evaluated && !w.pos.IsGameOver();
     w.leaf_color = c;
     return true;
   }
 
+  // SmartRetryCollisionPolicy::Handle (search.h:311-357): refork the colliding path where the
+  // runner-up is closest; false = abort.
+  static bool SmartRetryPrefix(const std::vector<PathElem>& path, std::vector<PathElem>* prefix) {
+    if (path.size() <= 1) { prefix->clear(); return true; }
+    int min_index = -1;
+    float min_diff = std::numeric_limits<float>::max();
+    for (int i = 0; i < (int)path.size(); ++i) {
+      if (path[i].action < 0 || path[i].top[1].first < 0) continue;
+      const float diff = std::abs(path[i].top[0].second - path[i].top[1].second);
+      if (diff < min_diff) { min_index = i; min_diff = diff; }
+    }
+    if (min_index < 0) return false;
+    prefix->assign(path.begin(), path.begin() + min_index + 1);
+    PathElem& e = prefix->back();
+    const TopActions t = e.top;
+    e.action = t[1].first;
+    e.top = TopActions{t[0], t[2], t[3], {-1, -10000.0f}};
+    return true;
+  }
+
+  void DescendRoundConcurrent() {   // SearchTask, search.cc:336-401, workers in order
+    backup_.clear();
+    n_evals_ = 0;
+    for (int& x : pending_level_) x = 0;
+    for (int wi = 0; wi < p_.batch; ++wi) {
+      Worker& w = workers_[wi];
+      w.aborted = false;
+      w.needs_eval = false;
+      std::vector<PathElem> prefix;
+      int retries = 0;
+      bool ok = Descend(w, prefix);
+      if (!ok) ++res_.num_collisions;
+      while (!ok) {
+        bool retry = false;
+        if (p_.collision != CollisionPolicy::kAbort && retries < p_.max_collision_retries) {
+          ++retries;
+          if (p_.collision == CollisionPolicy::kRetry) { prefix.clear(); retry = true; }
+          else retry = SmartRetryPrefix(w.path, &prefix);
+        }
+        if (!retry) break;
+        ok = Descend(w, prefix);
+      }
+      if (!ok) {
+        w.aborted = true;
+        w.path.clear();
+        ++res_.num_aborted;
+        continue;
+      }
+      for (int pi = 0; pi < (int)w.path.size(); ++pi)
+        backup_.push_back(BackupElem{pi, w.path[pi].node, w.path[pi].action, pi == (int)w.path.size() - 1});
+      if (w.needs_eval) {
+        w.eval_slot = n_evals_;
+        eval_pos_[n_evals_] = &w.pos;
+        eval_color_[n_evals_] = w.leaf_color;
+        eval_worker_[n_evals_] = wi;
+        ++n_evals_;
+      }
+    }
+  }
+
   void DescendRound() {   // search.cc:536-597
+    if (p_.mode == SearchMode::kConcurrent) { DescendRoundConcurrent(); return; }
     forks_.clear();
     stored_forks_.clear();
     backup_.clear();
     n_evals_ = 0;
+    for (int& x : pending_level_) x = 0;
     for (int wi = 0; wi < p_.batch; ++wi) {
       Worker& w = workers_[wi];
       w.aborted = false;
@@ -344,6 +469,8 @@ class BatchSearch {
   int eval_worker_[kMaxBatch];
   std::vector<p3hip_result> pending_;
   int n_evals_ = 0;
+  int pending_level_[8] = {};   // GlobalSearchState::pending_each_level
+  int stalled_rounds_ = 0;
 };
 
 }  // namespace p3

@@ -910,12 +910,24 @@ struct p3host_eval_stats {
 // Plays `num_games` evaluation games between two networks with the batch parallel search
 // (eval.cc:103-518).  engine_lib NULL/"" = NullEvaluator for both players.  One engine
 // instance per player, batch = num_games * leaves_per_round slots.
+static int g_eval_mode = 0, g_eval_qfn = 2, g_eval_nfn = 1, g_eval_collision = 0, g_eval_detector = 0;
+// Parallel-search knobs of subsequent p3host_eval_match calls (defaults = player_config.h:76-108:
+// concurrent rounds, virtual_loss_soft, virtual_visit, abort, noop).
+void p3host_eval_set_search(int mode, int q_fn, int n_fn, int collision, int detector) {
+  g_eval_mode = mode; g_eval_qfn = q_fn; g_eval_nfn = n_fn; g_eval_collision = collision; g_eval_detector = detector;
+}
+
 int p3host_eval_match(const char* engine_lib, const char* cur_weights, const char* cand_weights, int device,
                       int num_games, int visits_per_move, int leaves_per_round, int max_moves, int num_threads,
                       uint64_t seed, p3host_eval_stats* out, char* err) {
   EvalPlayerConfig pc;
   pc.n = visits_per_move;
   pc.num_threads_per_game = leaves_per_round;
+  pc.search_mode = (SearchMode)g_eval_mode;
+  pc.q_fn = (QFn)g_eval_qfn;
+  pc.n_fn = (NFn)g_eval_nfn;
+  pc.collision_policy = (CollisionPolicy)g_eval_collision;
+  pc.collision_detector = (CollisionDetector)g_eval_detector;
   const int slots = num_games * leaves_per_round;
   std::unique_ptr<Evaluator> ev[2];
   const bool use_null = !engine_lib || !engine_lib[0];

@@ -17,9 +17,10 @@ def L(built):
     return lib
 
 
-def run(L, batch, budget):
+def run(L, batch, budget, mode=1, q_fn=0, n_fn=0, collision=0, detector=0):
     out = np.zeros(10, np.int32)
-    assert L.p3host_test_batch_search(batch, budget, out.ctypes.data) == 0
+    L.p3host_test_batch_search_ex.argtypes = [C.c_int] * 7 + [C.c_void_p]
+    assert L.p3host_test_batch_search_ex(batch, budget, mode, q_fn, n_fn, collision, detector, out.ctypes.data) == 0
     return out
 
 
@@ -76,3 +77,45 @@ def test_eval_match_legacy_single_thread_path(built):
     assert st.games == 4 and st.cur_wins + st.cand_wins + st.draws == 4 and st.moves == 4 * 16
     assert st.visits == 12 * st.moves and st.collisions == 0
     assert st.positions <= st.visits + st.moves
+
+
+@pytest.mark.parametrize("q_fn,n_fn,collision,detector", [
+    (2, 1, 0, 0),    # defaults of player_config.h: virtual_loss_soft, virtual_visit, abort, noop
+    (1, 1, 0, 0),    # hard virtual loss
+    (0, 1, 2, 0),    # search_test.cc MakeParams: identity Q, virtual visits, smart retry
+    (0, 0, 1, 0),    # plain retry
+    (2, 1, 2, 1), (2, 1, 0, 2), (2, 1, 2, 3),   # n-in-flight / level-saturation / product detectors
+])
+@pytest.mark.parametrize("batch,budget", [(4, 32), (1, 16), (2, 24), (16, 2000)])
+def test_concurrent_round_mode(L, batch, budget, q_fn, n_fn, collision, detector):
+    """SearchTask's round structure (search.cc:336-458) with the virtual-loss Q / N functions,
+    collision policies and detectors (search.h:28-39,247-485, search_policy.h:400-459): same
+    invariants as the reference's tests (search_test.cc:130-222), plus a consistent tree."""
+    if detector in (1, 3) and batch < 4:
+        pytest.skip("threshold log2(batch) = 1: the n-in-flight detector fires on every descent")
+    o = run(L, batch, budget, 0, q_fn, n_fn, collision, detector)
+    visits, aborted, collisions, rounds, root_n, move = o[:6]
+    assert budget <= visits < budget + batch
+    assert move >= 0 and root_n > 1
+    assert o[7] == 0 and o[8] == 0
+    assert root_n == 1 + o[6] == 1 + visits
+    assert rounds * batch == visits + aborted and aborted <= collisions
+    if batch == 1:
+        assert collisions == 0
+
+
+def test_virtual_loss_spreads_a_round(L):
+    """Identity Q / N in a concurrent round sends every worker down the same path (all but the
+    first collide at the pending leaf and abort); virtual visits + virtual loss make the
+    workers of one round take different root moves, so far fewer descents are wasted."""
+    plain = run(L, 8, 64, 0, 0, 0, 0, 0)
+    vl = run(L, 8, 64, 0, 2, 1, 0, 0)
+    assert plain[1] > 5 * max(vl[1], 1) and vl[3] < plain[3]
+
+
+def test_fruitless_rounds_end_the_search(L):
+    """Two workers with the n-in-flight detector: threshold max(1, log2(2)) = 1 fires on every
+    entry into an existing child, so once the root's legal moves are expanded no descent can
+    complete; the search gives up instead of spinning (the reference would not terminate)."""
+    o = run(L, 2, 5000, 0, 2, 1, 0, 1)
+    assert 0 < o[0] < 5000 and o[5] >= 0 and o[8] == 0

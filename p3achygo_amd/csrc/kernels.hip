@@ -210,6 +210,18 @@ __global__ void __launch_bounds__(kWG, 2) k_init(InitArgs a) {
     }
     gsv[7] = (color == 1 ? -1.0f : 1.0f) * (*(const float*)(f + FeatOff::komi)) / 15.0f;
 
+    // game-state dense once per position: thread c computes (gs . Wg + b)[c] into LDS (the
+    // area behind the weight ring); the first ring acquire of the K loop below is the barrier
+    // that publishes it.  (Each lane used to fetch its 32 channels' 8 x 4 weights from L2 in
+    // the epilogue of every output pass.)
+    float* bias_lds = (float*)(smem + kRingOff + ring_bytes(CP));
+    if (threadIdx.x < C) {
+      float b = a.game_b[threadIdx.x];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) b += a.game_w[k * C + threadIdx.x] * gsv[k];
+      bias_lds[threadIdx.x] = b;
+    }
+
 #pragma unroll 1
     for (int cp = 0; cp < C / CP; ++cp) {
       f32x16 acc[2][T::NT];
@@ -221,12 +233,7 @@ __global__ void __launch_bounds__(kWG, 2) k_init(InitArgs a) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int c = cp * CP + acc_chan<G, CP>(mt, g4);
-          f32x4 bias = *(const f32x4*)(a.game_b + c);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const f32x4 w = *(const f32x4*)(a.game_w + k * C + c);
-            bias += w * gsv[k];
-          }
+          const f32x4 bias = *(const f32x4*)(bias_lds + c);
 #pragma unroll
           for (int j = 0; j < T::NT; ++j) {
             const int t = lg + j * T::LG;
@@ -855,9 +862,9 @@ static hipError_t set_lds(K kernel, size_t lds) {
 
 hipError_t launch_init(int C, const InitArgs& a, int grid, hipStream_t s) {
   using G = Geo<1, 16, 5>;
-  constexpr size_t lds = G::ACT_BYTES + ring_bytes(128);
+  constexpr size_t lds = G::ACT_BYTES + ring_bytes(128) + 384 * 4;   // + the game-state bias vector
   if (C == 192) {
-    constexpr size_t lds64 = G::ACT_BYTES + ring_bytes(64);
+    constexpr size_t lds64 = G::ACT_BYTES + ring_bytes(64) + 192 * 4;
     hipLaunchKernelGGL((k_init<192, 64>), dim3(grid), dim3(kWG), lds64, s, a);
   } else if (C == 384) {
     hipLaunchKernelGGL((k_init<384>), dim3(grid), dim3(kWG), lds, s, a);

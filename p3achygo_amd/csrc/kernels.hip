@@ -449,6 +449,13 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
   for (int i = threadIdx.x * 16; i < (int)kTtBytes; i += kWG * 16) *(f32x4*)(smem + i) = f32x4{0, 0, 0, 0};
   Ring<16384> ring;
   ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
+  // epilogue parameters (dense bias per board point, folded BN per channel) live in LDS behind
+  // the ring: fetched once per workgroup instead of from L2 after every K loop
+  float* p_bias = (float*)(smem + kRingOff + ring_bytes(128));
+  float* p_scale = p_bias + 384;
+  float* p_shift = p_scale + C;
+  for (int i = threadIdx.x; i < 384; i += kWG) p_bias[i] = i < kNLoc ? a.bias[i] : 0.0f;
+  for (int i = threadIdx.x; i < C; i += kWG) { p_scale[i] = a.scale[i]; p_shift[i] = a.shift[i]; }
   lds_barrier();
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -508,12 +515,12 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
         for (int mt = 0; mt < 2; ++mt) {
           const int j = jp * 128 + jg * 64 + mt * 32 + lr;
           if (j >= kNLoc) continue;
-          const float bj = a.bias[j];
+          const float bj = p_bias[j];
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const int c = half * CH + ct * 32 + g4 * 8 + h * 4;
-            const f32x4 sc = *(const f32x4*)(a.scale + c);
-            const f32x4 sh = *(const f32x4*)(a.shift + c);
+            const f32x4 sc = *(const f32x4*)(p_scale + c);
+            const f32x4 sh = *(const f32x4*)(p_shift + c);
             h4 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = (_Float16)mish_f((acc[mt][g4 * 4 + i] + bj) * sc[i] + sh[i]);
@@ -960,7 +967,7 @@ hipError_t launch_lconv(int kw, int cin, int cout, const LConvArgs& a, int grid,
 }
 
 hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s) {
-  constexpr size_t lds = 128 * kTtStride + ring_bytes(128);
+  constexpr size_t lds = 128 * kTtStride + ring_bytes(128) + (384 + 2 * 384) * 4;   // + epilogue parameters
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = set_lds(k_bdense<256>, lds);

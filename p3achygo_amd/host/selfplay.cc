@@ -953,40 +953,52 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
   const auto t0 = std::chrono::steady_clock::now();
   // every game starts wanting evaluations from the engine of its side to move
   pool.ParallelFor(num_games, [&](int g) { want[g] = games[g]->Step(); });
+  std::vector<int> eng_of(num_games, -1);
   for (;;) {
-    bool any = false;
-    for (int e = 0; e < 2; ++e) {
-      int total = 0;
-      for (int g = 0; g < num_games; ++g) {
-        base[g] = -1;
-        if (want[g] > 0 && games[g]->active_engine() == e) { base[g] = total; total += want[g]; }
-      }
-      if (total == 0) continue;
-      any = true;
-      pool.ParallelFor(num_games, [&](int g) {
-        if (base[g] < 0) return;
-        for (int i = 0; i < want[g]; ++i) {
-          games[g]->FillEval(i, &feats[base[g] + i]);
-          ev[e]->Load(base[g] + i, feats[base[g] + i]);
-        }
-      });
-      if (!ev[e]->Run()) {
-        if (err) snprintf(err, 256, "engine run failed");
-        return 2;
-      }
-      positions += total;
-      ++batches;
-      pool.ParallelFor(num_games, [&](int g) {
-        if (base[g] < 0) return;
-        p3hip_result r;
-        for (int i = 0; i < want[g]; ++i) {
-          ev[e]->Get(base[g] + i, r);
-          games[g]->Deliver(i, r);
-        }
-        want[g] = games[g]->Step();
-      });
+    // Every game wants leaves from the engine of its side to move: fill both engines' batches,
+    // run the two forward passes CONCURRENTLY (own streams on the same device), hand back.
+    int total[2] = {0, 0};
+    for (int g = 0; g < num_games; ++g) {
+      base[g] = -1;
+      eng_of[g] = -1;
+      if (want[g] <= 0) continue;
+      const int e = games[g]->active_engine();
+      eng_of[g] = e;
+      base[g] = total[e];
+      total[e] += want[g];
     }
-    if (!any) break;
+    if (total[0] + total[1] == 0) break;
+    pool.ParallelFor(num_games, [&](int g) {
+      if (base[g] < 0) return;
+      const int e = eng_of[g];
+      // the two engines' slot ranges share `feats`: engine 1's rows start after engine 0's
+      p3hip_features* f = &feats[(e == 0 ? 0 : total[0]) + base[g]];
+      for (int i = 0; i < want[g]; ++i) {
+        games[g]->FillEval(i, f + i);
+        ev[e]->Load(base[g] + i, f[i]);
+      }
+    });
+    bool ok[2] = {true, true};
+    std::thread second;
+    if (total[1] > 0) second = std::thread([&] { ok[1] = ev[1]->Run(); });
+    if (total[0] > 0) ok[0] = ev[0]->Run();
+    if (second.joinable()) second.join();
+    if (!ok[0] || !ok[1]) {
+      if (err) snprintf(err, 256, "engine run failed");
+      return 2;
+    }
+    positions += total[0] + total[1];
+    batches += (total[0] > 0) + (total[1] > 0);
+    pool.ParallelFor(num_games, [&](int g) {
+      if (base[g] < 0) return;
+      const int e = eng_of[g];
+      p3hip_result r;
+      for (int i = 0; i < want[g]; ++i) {
+        ev[e]->Get(base[g] + i, r);
+        games[g]->Deliver(i, r);
+      }
+      want[g] = games[g]->Step();
+    });
   }
   if (out) {
     std::memset(out, 0, sizeof *out);

@@ -123,12 +123,13 @@ void pack_segment(std::vector<_Float16>& dst, const float* W, int taps, int ntap
 
 struct FoldedBN { size_t scale_off, shift_off; };
 
-// One conv launch of a layer-wise block (kind 4).  Buffers: 0 = x (C), 1 = t, 2 = u.
+// One conv launch of a layer-wise block (kind 4).  Regions: 0 = x; 1, 2 = the two C_b-channel
+// halves of the scratch buffer t; 3, 4 = those of u (3 also names u as a whole C-channel buffer).
 struct LayerPlan {
   int kw, cin, cout;
-  int pre_bn, act_bn;   // index into BlockPlan::bn, or -1
-  int res;              // residual accumulate into the output buffer
-  int in_buf, out_buf;
+  bool pre, act, res, dual;   // see p3::LConvArgs
+  FoldedBN pre_bn, out_bn;    // prologue / epilogue BN (epilogue: of act or of dual's second output)
+  int in_buf, out_buf, out2_buf;
   size_t stream_off = 0;
   int nms = 0;
 };
@@ -242,12 +243,14 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
     e->game_w_off = ar.add(wf.get("init_game.w").data, 8 * C * 4);
     e->game_b_off = ar.add(wf.get("init_game.b").data, C * 4);
   }
+  bool have_xa = false;   // layer-wise path: u holds mish(bn0(x)) of the next block
   for (int i = 0; i < wf.nblocks; ++i) {
     BlockPlan bp;
     const std::string p = "blocks." + std::to_string(i);
     auto W = [&](int j) { return wf.get(p + ".conv" + std::to_string(j) + ".w").data; };
     if (wf.is_broadcast(i)) {
       bp.kind = 3;
+      have_xa = false;
       bp.bn[0] = fold_bn(ar, wf, p + ".bn0");
       bp.bn[1] = fold_bn(ar, wf, p + ".bn1");
       const int CPb = (CB == 128) ? 128 : 64;
@@ -275,33 +278,46 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
       bp.kind = 4;
       const int nconv = classic ? 2 : ((wf.btype == 0) ? wf.inner + 2 : 6);
       for (int j = 0; j < nconv; ++j) bp.bn[j] = fold_bn(ar, wf, p + ".bn" + std::to_string(j));
-      auto add_layer = [&](int j, int kw, int cin, int cout, int pre_bn, int act_bn, int res, int in_buf, int out_buf) {
-        LayerPlan lp{kw, cin, cout, pre_bn, act_bn, res, in_buf, out_buf};
+      // The consumer's prologue (BN + mish of its input) is applied ONCE by the producer: a
+      // layer either stores its output already activated for the next conv (act), or stores it
+      // raw and a second, activated copy (dual).  Only the first layer after the init conv or
+      // a broadcast block still activates its input while staging (pre) — every workgroup of
+      // an output pass would otherwise redo that VALU work.  `xa` = activated copy of x, in u.
+      FoldedBN next_bn0{};
+      const bool next_layerwise = i + 1 < wf.nblocks && !wf.is_broadcast(i + 1);
+      if (next_layerwise) next_bn0 = fold_bn(ar, wf, "blocks." + std::to_string(i + 1) + ".bn0");
+      const FoldedBN none{};
+      auto add_layer = [&](int j, int kw, int cin, int cout, bool pre, const FoldedBN& pre_bn, bool act, bool res,
+                           bool dual, const FoldedBN& out_bn, int in_buf, int out_buf, int out2_buf) {
+        LayerPlan lp{kw, cin, cout, pre, act, res, dual, pre_bn, out_bn, in_buf, out_buf, out2_buf};
         std::vector<_Float16> s;
         for (int cp = 0; cp < cout / 64; ++cp)
           for (int ip = 0; ip < cin / 64; ++ip) pack_segment(s, W(j), kw * kw, kw * kw, cin, cout, ip * 64, 64, cp * 64, 64);
         lp.stream_off = add_stream(ar, s, lp.nms, 64);
         bp.layers.push_back(lp);
       };
+      const bool from_xa = have_xa;          // first layer input: activated copy in u, or raw x with pre
+      const int in0 = from_xa ? 3 : 0;
       if (classic) {         // x + conv3(act1(conv3(act0(x)))), model.py:330-368
-        add_layer(0, 3, C, C, 0, 1, 0, 0, 1);
-        add_layer(1, 3, C, C, -1, -1, 1, 1, 0);
-      } else if (wf.btype == 0) {   // btl: every inner input is produced already activated
-        add_layer(0, 1, C, Cb, 0, 1, 0, 0, 1);
+        add_layer(0, 3, C, C, !from_xa, bp.bn[0], true, false, false, bp.bn[1], in0, 1, -1);
+        add_layer(1, 3, C, C, false, none, false, true, next_layerwise, next_bn0, 1, 0, 3);
+      } else if (wf.btype == 0) {   // btl
+        add_layer(0, 1, C, Cb, !from_xa, bp.bn[0], true, false, false, bp.bn[1], in0, 1, -1);
         int cur = 1;
         for (int j = 1; j <= wf.inner; ++j) {
-          add_layer(j, 3, Cb, Cb, -1, j + 1, 0, cur, 3 - cur);
+          add_layer(j, 3, Cb, Cb, false, none, true, false, false, bp.bn[j + 1], cur, 3 - cur, -1);
           cur = 3 - cur;
         }
-        add_layer(wf.inner + 1, 1, Cb, C, -1, -1, 1, cur, 0);
-      } else {               // nbt: the inner residual stream t stays raw in buffer 1
-        add_layer(0, 1, C, Cb, 0, -1, 0, 0, 1);
-        add_layer(1, 3, Cb, Cb, 1, 2, 0, 1, 2);
-        add_layer(2, 3, Cb, Cb, -1, -1, 1, 2, 1);
-        add_layer(3, 3, Cb, Cb, 3, 4, 0, 1, 2);
-        add_layer(4, 3, Cb, Cb, -1, -1, 1, 2, 1);
-        add_layer(5, 1, Cb, C, 5, -1, 1, 1, 0);
+        add_layer(wf.inner + 1, 1, Cb, C, false, none, false, true, next_layerwise, next_bn0, cur, 0, 3);
+      } else {               // nbt: the inner residual stream t stays raw in region 1
+        add_layer(0, 1, C, Cb, !from_xa, bp.bn[0], false, false, true, bp.bn[1], in0, 1, 2);   // t, act1(t)
+        add_layer(1, 3, Cb, Cb, false, none, true, false, false, bp.bn[2], 2, 3, -1);
+        add_layer(2, 3, Cb, Cb, false, none, false, true, true, bp.bn[3], 3, 1, 2);             // t' = t + ., act3(t')
+        add_layer(3, 3, Cb, Cb, false, none, true, false, false, bp.bn[4], 2, 3, -1);
+        add_layer(4, 3, Cb, Cb, false, none, false, true, true, bp.bn[5], 3, 1, 2);             // t'', act5(t'')
+        add_layer(5, 1, Cb, C, false, none, false, true, next_layerwise, next_bn0, 2, 0, 3);
       }
+      have_xa = next_layerwise;
     } else {
       bp.kind = wf.btype;
       const int nconv = (wf.btype == 0) ? wf.inner + 2 : 6;
@@ -398,14 +414,16 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
       c1.wstream = e->d_arena + bp.stream3_off; c1.nms_total = bp.nms3;
       if (!e->check(p3::launch_conv1x1(C, 1, c1, e->n_cu, s), "launch conv_last")) return false;
     } else if (bp.kind == 4) {
-      _Float16* bufs[3] = {e->d_x, e->d_t, e->d_u};
+      const size_t half = (size_t)e->batch * wf.Cb * kNLoc;   // elements of one C_b-channel tensor
+      _Float16* bufs[5] = {e->d_x, e->d_t, e->d_t + half, e->d_u, e->d_u + half};
       for (const LayerPlan& lp : bp.layers) {
         p3::LConvArgs a{};
         a.in = bufs[lp.in_buf]; a.out = bufs[lp.out_buf]; a.npos = npos;
+        a.out2 = lp.out2_buf >= 0 ? bufs[lp.out2_buf] : nullptr;
         a.wstream = e->d_arena + lp.stream_off; a.nms_total = lp.nms;
-        a.pre = lp.pre_bn >= 0; a.act = lp.act_bn >= 0; a.res = lp.res;
-        if (a.pre) { a.scale_in = e->dev<float>(bp.bn[lp.pre_bn].scale_off); a.shift_in = e->dev<float>(bp.bn[lp.pre_bn].shift_off); }
-        if (a.act) { a.scale_out = e->dev<float>(bp.bn[lp.act_bn].scale_off); a.shift_out = e->dev<float>(bp.bn[lp.act_bn].shift_off); }
+        a.pre = lp.pre; a.act = lp.act; a.res = lp.res; a.dual = lp.dual;
+        if (a.pre) { a.scale_in = e->dev<float>(lp.pre_bn.scale_off); a.shift_in = e->dev<float>(lp.pre_bn.shift_off); }
+        if (a.act || a.dual) { a.scale_out = e->dev<float>(lp.out_bn.scale_off); a.shift_out = e->dev<float>(lp.out_bn.shift_off); }
         if (!e->check(p3::launch_lconv(lp.kw, lp.cin, lp.cout, a, e->n_cu, s), "launch k_lconv")) return false;
       }
     } else {

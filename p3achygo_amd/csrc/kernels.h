@@ -58,14 +58,16 @@ struct Conv1x1Args {
 };
 
 // One conv layer of the layer-wise path (k_lconv): y = conv(in') [+ y], in' = mish(bn_in(in))
-// when pre != 0, y' = mish(bn_out(y)) stored instead of y when act != 0.
+// when pre != 0; act: mish(bn_out(y)) stored instead of y; dual: y stored to `out` AND
+// mish(bn_out(y)) to `out2` (the consumer's prologue applied once by the producer).
 struct LConvArgs {
   const _Float16* in;   // [npos][CIN/8][361][8]
   _Float16* out;        // [npos][COUT/8][361][8]; read as the residual when res != 0
+  _Float16* out2;       // dual != 0: mish(bn_out(y)) goes here, the raw y (after the residual add) to `out`
   int npos;
   const void* wstream;
   int nms_total;
-  int pre, act, res;
+  int pre, act, res, dual;
   const float *scale_in, *shift_in;    // folded BN of the prologue   [CIN]
   const float *scale_out, *shift_out;  // folded BN of the epilogue   [COUT]
 };

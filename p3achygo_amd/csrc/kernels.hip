@@ -365,8 +365,9 @@ __global__ void __launch_bounds__(kWG, 2) k_conv1x1(Conv1x1Args a) {
 //                                        so inner layers stage without VALU work)
 //   res : out += acc                    (residual, in place)
 // =======================================================================================
-template <int KW, int CIN, int COUT, bool PRE, bool ACT, bool RES>
+template <int KW, int CIN, int COUT, bool PRE, bool ACT, bool RES, bool DUAL = false>
 __global__ void __launch_bounds__(kWG, 2) k_lconv(LConvArgs a) {
+  static_assert(!(ACT && DUAL), "act stores the activated tensor only, dual stores both");
   constexpr int CB = 64, NPOS = 2, CP = 64;
   using G = Geo<NPOS, CB, KW>;
   using T = Tiling<G, CP>;
@@ -402,8 +403,9 @@ __global__ void __launch_bounds__(kWG, 2) k_lconv(LConvArgs a) {
         pending_stores = 0;
         conv_segment<G, CP, KW, KW * KW>(ring, smem, acc);
       }
-      pending_stores = 24;
-      if (ACT) {   // parameters are fetched one channel quad at a time: the prefetched slice stays in registers
+      // BN + mish of the output in place; parameters are fetched one channel quad at a time so
+      // the prefetched slice stays in registers
+      auto activate = [&]() {
         const int c0 = cp * CP + cg_of<G, CP>() * 64 + (launder(threadIdx.x & 63) >> 5) * 4;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -415,8 +417,28 @@ __global__ void __launch_bounds__(kWG, 2) k_lconv(LConvArgs a) {
               acc[k >> 2][j][(k & 3) * 4 + i] = mish_f(acc[k >> 2][j][(k & 3) * 4 + i] * sc[i] + sh[i]);
           __builtin_amdgcn_sched_barrier(0);
         }
+      };
+      if (DUAL) {
+        ResRegs<G, CP, T::NT> rr;
+        residual_addr<G, CP, T::NT>(rr, COUT, pos0, a.npos, cp * CP);
+        if (RES) {
+          residual_load<G, CP, T::NT>(rr, a.out);
+#pragma unroll
+          for (int j = 0; j < T::NT; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[k >> 2][j][(k & 3) * 4 + i] += (float)rr.rv[j][k][i];
+        }
+        epilogue_store<G, CP, false, T::NT>(acc, rr, a.out);    // raw y
+        activate();
+        epilogue_store<G, CP, false, T::NT>(acc, rr, a.out2);   // the consumer's input, activated once here
+        pending_stores = 36;   // 48 stores are in flight; under-noting only makes the next acquires stricter
+      } else {
+        pending_stores = 24;
+        if (ACT) activate();
+        epilogue_to_global<G, CP, RES>(acc, a.out, COUT, pos0, a.npos, cp * CP);
       }
-      epilogue_to_global<G, CP, RES>(acc, a.out, COUT, pos0, a.npos, cp * CP);
     }
   }
   lds_barrier();
@@ -934,35 +956,39 @@ hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipS
   return hipErrorInvalidValue;
 }
 
-template <int KW, int CIN, int COUT, bool PRE, bool ACT, bool RES>
+template <int KW, int CIN, int COUT, bool PRE, bool ACT, bool RES, bool DUAL>
 static hipError_t launch_lconv_t(const LConvArgs& a, int n_cu, hipStream_t s) {
   using G = Geo<2, 64, KW>;
   const int grid = conv_split_grid(a.npos, 2, COUT / 64, n_cu);
   constexpr size_t lds = G::ACT_BYTES + ring_bytes(64);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = set_lds(k_lconv<KW, CIN, COUT, PRE, ACT, RES>, lds);
+    hipError_t e = set_lds(k_lconv<KW, CIN, COUT, PRE, ACT, RES, DUAL>, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_lconv<KW, CIN, COUT, PRE, ACT, RES>), dim3(grid), dim3(kWG), lds, s, a);
+  hipLaunchKernelGGL((k_lconv<KW, CIN, COUT, PRE, ACT, RES, DUAL>), dim3(grid), dim3(kWG), lds, s, a);
   return hipGetLastError();
 }
 
-// the seven layer shapes of C=384 / C_b=192 btl and nbt blocks (engine.cpp build_plan)
+// the layer shapes of the C=384 / C_b=192 btl and nbt blocks and of the C=192 classic blocks
+// (engine.cpp build_plan); f = pre, act, res, dual
 hipError_t launch_lconv(int kw, int cin, int cout, const LConvArgs& a, int grid, hipStream_t s) {   // grid = CU count
-  const int f = (a.pre ? 4 : 0) | (a.act ? 2 : 0) | (a.res ? 1 : 0);
-  if (kw == 1 && cin == 384 && cout == 192) {
-    if (f == 6) return launch_lconv_t<1, 384, 192, true, true, false>(a, grid, s);    // btl reduce
-    if (f == 4) return launch_lconv_t<1, 384, 192, true, false, false>(a, grid, s);   // nbt reduce
-  } else if (kw == 3 && cin == 192 && cout == 192) {
-    if (f == 2) return launch_lconv_t<3, 192, 192, false, true, false>(a, grid, s);   // btl inner
-    if (f == 6) return launch_lconv_t<3, 192, 192, true, true, false>(a, grid, s);    // nbt conv1 / conv3
-    if (f == 1) return launch_lconv_t<3, 192, 192, false, false, true>(a, grid, s);   // nbt conv2 / conv4
-  } else if (kw == 1 && cin == 192 && cout == 384) {
-    if (f == 1) return launch_lconv_t<1, 192, 384, false, false, true>(a, grid, s);   // btl expand
-    if (f == 5) return launch_lconv_t<1, 192, 384, true, false, true>(a, grid, s);    // nbt expand
-  }
+  const int f = (a.pre ? 8 : 0) | (a.act ? 4 : 0) | (a.res ? 2 : 0) | (a.dual ? 1 : 0);
+#define P3_LCONV(KW, CIN, COUT, PRE, ACT, RES, DUAL) \
+  if (kw == KW && cin == CIN && cout == COUT && f == ((PRE ? 8 : 0) | (ACT ? 4 : 0) | (RES ? 2 : 0) | (DUAL ? 1 : 0))) \
+    return launch_lconv_t<KW, CIN, COUT, PRE, ACT, RES, DUAL>(a, grid, s);
+  P3_LCONV(1, 384, 192, true, true, false, false)     // btl reduce from the raw stream
+  P3_LCONV(1, 384, 192, false, true, false, false)    // btl reduce from the activated copy
+  P3_LCONV(1, 384, 192, true, false, false, true)     // nbt reduce (t raw + act1(t))
+  P3_LCONV(1, 384, 192, false, false, false, true)
+  P3_LCONV(3, 192, 192, false, true, false, false)    // inner conv, activated output
+  P3_LCONV(3, 192, 192, true, true, false, false)     // classic conv0 from the raw stream
+  P3_LCONV(3, 192, 192, false, false, true, false)    // classic conv1 (+x), last block
+  P3_LCONV(3, 192, 192, false, false, true, true)     // nbt conv2 / conv4 (t' raw + act(t')), classic conv1 (+x, + next act)
+  P3_LCONV(1, 192, 384, false, false, true, false)    // expand + x
+  P3_LCONV(1, 192, 384, false, false, true, true)     // expand + x, + the next block's activated input
+#undef P3_LCONV
   return hipErrorInvalidValue;
 }
 

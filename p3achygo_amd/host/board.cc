@@ -341,7 +341,8 @@ void Board::CalculatePassAliveRegionForColor(Color color) {
   for (int p = 0; p < kNumLocs; ++p)
     if (stones_[p] == color && gid_[p] == p) {
       group_slot[p] = (int16_t)groups.size();
-      groups.push_back(Group{(int16_t)p});
+      groups.emplace_back();
+      groups.back().head = (int16_t)p;
     }
   if (groups.empty()) return;
 

@@ -354,7 +354,25 @@ class GameRunner {
       fork_.reset(new ForkManager(cfg_.fork_params, cfg_.reuse, prob_, /*started_from_forced_search=*/!is_fresh_game));
     forking_ = side_pending_ = false;
     cache_.Clear();
+    if (game_->IsGameOver() || game_->num_moves() >= cfg_.max_moves) {
+      // A restart state can already be finished (a fork whose alternative move was the second
+      // pass): the reference's game loop (self_play_thread.cc:427-428) is then skipped and the
+      // game is scored and recorded as it stands.
+      FinishGame();
+      return;
+    }
     BeginSearch();
+  }
+
+  void FinishGame() {   // self_play_thread.cc:900-912
+    game_->WriteResult();
+    ++stats_.games;
+    if (game_->result().winner == kBlack) ++stats_.black_wins;
+    last_result_ = game_->result();
+    last_moves_ = game_->moves();
+    if (fork_) fork_->FinalizeGame(*game_, prob_);
+    if (cfg_.recorder) cfg_.recorder->RecordGame(init_board_, *game_, std::move(move_infos_));
+    NewGame();
   }
 
   void BeginSearch() {   // self_play_thread.cc:429-611
@@ -488,14 +506,7 @@ class GameRunner {
     pool_.Reap(next);   // self_play_thread.cc:711-722
     root_ = next;
     if (game_->IsGameOver() || game_->num_moves() >= cfg_.max_moves) {
-      game_->WriteResult();
-      ++stats_.games;
-      if (game_->result().winner == kBlack) ++stats_.black_wins;
-      last_result_ = game_->result();
-      last_moves_ = game_->moves();
-      if (fork_) fork_->FinalizeGame(*game_, prob_);
-      if (cfg_.recorder) cfg_.recorder->RecordGame(init_board_, *game_, std::move(move_infos_));
-      NewGame();
+      FinishGame();
       return;
     }
     if (root_->is_terminal) {   // cannot happen while the game is not over; defensive reset

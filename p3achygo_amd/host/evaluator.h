@@ -1,0 +1,87 @@
+// evaluator.h — the engine boundary as the host sees it (mirrors nn::Engine,
+// cc/nn/engine/engine.h:22-43), with the two implementations the host links: the HIP engine
+// bound through its C ABI, and the reference tests' NullEngine.
+#pragma once
+#include <dlfcn.h>
+
+#include <cstring>
+#include <string>
+
+#include "../../include/p3hip.h"
+#include "board.h"
+
+namespace p3 {
+
+// ---- evaluator boundary (mirrors nn::Engine, cc/nn/engine/engine.h:22-43) -------------
+struct Evaluator {
+  virtual ~Evaluator() = default;
+  virtual void Load(int slot, const p3hip_features& f) = 0;
+  virtual bool Run() = 0;
+  virtual void Get(int slot, p3hip_result& r) = 0;
+  virtual void GetOwnership(int slot, float out[P3HIP_NUM_LOCS]) { std::memset(out, 0, sizeof(float) * P3HIP_NUM_LOCS); }
+};
+
+// Uniform policy, even outcome, zero score: the reference's NullEngine
+// (cc/mcts/__tests__/search_test.cc:49-65).  Lets the host be tested without a GPU.
+struct NullEvaluator final : Evaluator {
+  void Load(int, const p3hip_features&) override {}
+  bool Run() override { return true; }
+  void Get(int, p3hip_result& r) override {
+    for (int i = 0; i < kNumMoves; ++i) {
+      r.move_logits[i] = 0.0f;
+      r.move_probs[i] = 1.0f / kNumMoves;
+      r.opt_move_probs[i] = 1.0f / kNumMoves;
+    }
+    r.value_probs[0] = r.value_probs[1] = 0.5f;
+    for (int i = 0; i < P3HIP_NUM_SCORE_LOGITS; ++i) r.score_probs[i] = 0.0f;
+    r.score_probs[400] = 1.0f;
+    r.err2_outcome = 0.0f;
+  }
+};
+
+// The HIP engine, bound through its C ABI exactly as a foreign host would bind it.
+struct HipEvaluator final : Evaluator {
+  void* lib = nullptr;
+  p3hip_engine* eng = nullptr;
+  decltype(&p3hip_create) create = nullptr;
+  decltype(&p3hip_destroy) destroy = nullptr;
+  decltype(&p3hip_load_slot) load = nullptr;
+  decltype(&p3hip_run) run = nullptr;
+  decltype(&p3hip_get_slot) get = nullptr;
+  decltype(&p3hip_get_ownership) get_own = nullptr;
+  decltype(&p3hip_last_error) last_error = nullptr;
+  decltype(&p3hip_create_error) create_error = nullptr;
+  std::string err;
+
+  bool Open(const char* lib_path, const char* weights, int batch, int device) {
+    lib = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { err = dlerror(); return false; }
+    create = (decltype(create))dlsym(lib, "p3hip_create");
+    destroy = (decltype(destroy))dlsym(lib, "p3hip_destroy");
+    load = (decltype(load))dlsym(lib, "p3hip_load_slot");
+    run = (decltype(run))dlsym(lib, "p3hip_run");
+    get = (decltype(get))dlsym(lib, "p3hip_get_slot");
+    get_own = (decltype(get_own))dlsym(lib, "p3hip_get_ownership");
+    last_error = (decltype(last_error))dlsym(lib, "p3hip_last_error");
+    create_error = (decltype(create_error))dlsym(lib, "p3hip_create_error");
+    if (!create || !destroy || !load || !run || !get) { err = "missing p3hip symbols"; return false; }
+    eng = create(weights, batch, 1, device, 0);
+    if (!eng) { err = create_error ? create_error() : "p3hip_create failed"; return false; }
+    return true;
+  }
+  ~HipEvaluator() override {
+    if (eng) destroy(eng);
+    if (lib) dlclose(lib);
+  }
+  void Load(int slot, const p3hip_features& f) override { load(eng, slot, &f); }
+  bool Run() override {
+    if (run(eng) != 0) { err = last_error(eng); return false; }
+    return true;
+  }
+  void Get(int slot, p3hip_result& r) override { get(eng, slot, &r); }
+  void GetOwnership(int slot, float out[P3HIP_NUM_LOCS]) override {
+    if (get_own) get_own(eng, slot, out);
+  }
+};
+
+}  // namespace p3

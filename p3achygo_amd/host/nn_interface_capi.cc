@@ -1,0 +1,235 @@
+// nn_interface_capi.cc — C entry points around NNInterface (nn_interface.h): a handle API so
+// a thread-per-game caller can be driven from ctypes, and the stress tests restated from
+// cc/nn/__tests__/nn_interface_sync_test.cc.
+#include <chrono>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "nn_interface.h"
+
+using namespace p3;
+
+namespace {
+
+// ---- the reference test's CountingEngine (nn_interface_sync_test.cc:73-175) ---------------
+// RunInference writes f(slot) into every element of every slot, yielding between slots;
+// GetBatch reads its slot element by element, yielding in between, and checks
+//   race:   all elements equal (no RunInference during the read),
+//   stale:  the result's generation is newer than the generation at LoadBatch,
+//   slot:   the value is f(slot).
+constexpr int kSlotElems = 32;
+constexpr int kPrime = (1 << 19) - 1;
+inline int SlotFn(int t) { return (t + t) % kPrime; }
+
+struct CountingEvaluator final : Evaluator {
+  explicit CountingEvaluator(int n) : n_(n), buf_(n * kSlotElems), result_gen_(n), load_gen_(n) {
+    for (auto& b : buf_) b.store(0);
+    for (auto& g : result_gen_) g.store(0);
+    for (auto& g : load_gen_) g.store(0);
+  }
+  void Load(int t, const p3hip_features&) override {
+    load_gen_[t].store(gen_.load(std::memory_order_acquire), std::memory_order_release);
+    ++loads_;
+  }
+  bool Run() override {
+    const int gen = gen_.fetch_add(1, std::memory_order_relaxed) + 1;
+    for (int t = 0; t < n_; ++t) {
+      const int v = SlotFn(t);
+      for (int i = 0; i < kSlotElems; ++i) buf_[t * kSlotElems + i].store(v, std::memory_order_relaxed);
+      result_gen_[t].store(gen, std::memory_order_relaxed);
+      std::this_thread::yield();
+    }
+    return true;
+  }
+  void Get(int t, p3hip_result& r) override {
+    int vals[kSlotElems];
+    for (int i = 0; i < kSlotElems; ++i) {
+      vals[i] = buf_[t * kSlotElems + i].load(std::memory_order_relaxed);
+      std::this_thread::yield();
+    }
+    for (int i = 1; i < kSlotElems; ++i)
+      if (vals[i] != vals[0]) race_ = true;
+    if (result_gen_[t].load(std::memory_order_relaxed) <= load_gen_[t].load(std::memory_order_acquire)) stale_ = true;
+    if (vals[0] != SlotFn(t)) wrong_slot_ = true;
+    std::memset(&r, 0, sizeof r);
+    for (float& x : r.move_logits) x = (float)vals[0];
+  }
+  int failures() const { return (race_ ? 1 : 0) | (stale_ ? 2 : 0) | (wrong_slot_ ? 4 : 0); }
+
+  const int n_;
+  std::atomic<int> gen_{0};
+  std::vector<std::atomic<int>> buf_, result_gen_, load_gen_;
+  std::atomic<bool> race_{false}, stale_{false}, wrong_slot_{false};
+  std::atomic<long> loads_{0};
+};
+
+// One worker of the reference's stress loop: jitter, occasional long sleeps (every 8th
+// thread misses several batches), then a blocking evaluation whose value must be f(slot).
+void StressWorker(int tid, NNInterface* black_nn, NNInterface* white_nn, std::atomic<bool>* stop,
+                  std::atomic<bool>* error, std::atomic<long>* calls) {
+  Game game;
+  Probability prob((uint64_t)tid);
+  std::mt19937 rng((uint32_t)tid * 2654435761u);
+  std::uniform_int_distribution<int> jitter_us(100, 1000), slow_ms(5, 50);
+  const bool slow = tid % 8 == 0;
+  int ply = 0;
+  while (!stop->load(std::memory_order_relaxed) && !error->load(std::memory_order_relaxed)) {
+    std::this_thread::sleep_for(std::chrono::microseconds(jitter_us(rng)));
+    if (slow) std::this_thread::sleep_for(std::chrono::milliseconds(slow_ms(rng)));
+    NNInterface* nn = ply % 2 == 0 ? black_nn : white_nn;
+    const p3hip_result r = nn->LoadAndGetInference(tid, game, kBlack, prob);
+    if ((int)r.move_logits[0] != SlotFn(tid)) {
+      error->store(true);
+      return;
+    }
+    calls->fetch_add(1, std::memory_order_relaxed);
+    ++ply;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// RunSyncTest / RunDualInterfaceTest (nn_interface_sync_test.cc:178-355).  strategy: 0
+// kMutex, 1 kGenCounter.  Returns a failure mask: 1 race, 2 stale, 4 wrong slot, 8 worker
+// saw a wrong value (second interface's bits shifted by 4); *calls_out = evaluations done.
+int p3host_test_nn_sync(int strategy, int num_threads, int millis, int cache_size, int dual, long* calls_out) {
+  auto* ea = new CountingEvaluator(num_threads);
+  auto* eb = dual ? new CountingEvaluator(num_threads) : nullptr;
+  std::atomic<bool> stop{false}, error{false};
+  std::atomic<long> calls{0};
+  int mask = 0;
+  {
+    NNInterface nn_a(num_threads, 200, (size_t)cache_size, std::unique_ptr<Evaluator>(ea),
+                     (NNInterface::WakeStrategy)strategy);
+    std::unique_ptr<NNInterface> nn_b;
+    if (dual)
+      nn_b.reset(new NNInterface(num_threads, 200, (size_t)cache_size, std::unique_ptr<Evaluator>(eb),
+                                 (NNInterface::WakeStrategy)strategy));
+    std::vector<std::thread> workers;
+    for (int t = 0; t < num_threads; ++t) {
+      NNInterface* black = &nn_a;
+      NNInterface* white = &nn_a;
+      if (dual) {   // cur plays black in even games, white in odd ones
+        black = t % 2 == 0 ? &nn_a : nn_b.get();
+        white = t % 2 == 0 ? nn_b.get() : &nn_a;
+      }
+      workers.emplace_back(StressWorker, t, black, white, &stop, &error, &calls);
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(millis));
+    stop.store(true);
+    for (auto& w : workers) w.join();
+    mask = ea->failures() | (error.load() ? 8 : 0);
+    if (dual) mask |= eb->failures() << 4;
+  }
+  if (calls_out) *calls_out = calls.load();
+  return mask;
+}
+
+// The async path parallel search uses (nn_interface.h:176-198, search.cc's SearchTask):
+// `tasks` search tasks share one interface in kExplicit mode; each owns `workers` slots,
+// loads them all, signals once, then fetches them all.  Returns the same failure mask.
+int p3host_test_nn_async(int strategy, int tasks, int workers, int rounds, long* inferences_out) {
+  const int n = tasks * workers;
+  auto* eng = new CountingEvaluator(n);
+  std::atomic<bool> error{false};
+  int mask = 0;
+  {
+    NNInterface nn(n, NNInterface::kTimeoutUs, 0, std::unique_ptr<Evaluator>(eng), NNInterface::SignalKind::kExplicit,
+                   tasks, (NNInterface::WakeStrategy)strategy);
+    std::vector<std::thread> threads;
+    for (int t = 0; t < tasks; ++t)
+      threads.emplace_back([&, t] {
+        NNInterface::Slot slot = nn.MakeSlot(t * workers);
+        Game game;
+        Probability prob((uint64_t)t);
+        std::mt19937 rng(t + 1);
+        for (int r = 0; r < rounds && !error.load(); ++r) {
+          if (rng() % 4 == 0) std::this_thread::sleep_for(std::chrono::microseconds(rng() % 700));
+          for (int w = 0; w < workers; ++w) slot.LoadEntry(w, game, kBlack, prob);
+          slot.SignalReadyForInference();
+          for (int w = 0; w < workers; ++w) {
+            const p3hip_result res = slot.FetchEntry(w, game, kBlack);
+            if ((int)res.move_logits[0] != SlotFn(t * workers + w)) error.store(true);
+          }
+        }
+        slot.UnregisterSearchTask();
+      });
+    for (auto& th : threads) th.join();
+    mask = eng->failures() | (error.load() ? 8 : 0);
+    if (inferences_out) *inferences_out = nn.num_inferences();
+  }
+  return mask;
+}
+
+// ---- handle API ----------------------------------------------------------------------------
+// engine_kind: 0 the uniform NullEvaluator, 1 the HIP engine (lib_path, weights, device).
+void* p3host_nn_new(int engine_kind, const char* lib_path, const char* weights, int device, int num_threads,
+                    long timeout_us, long cache_size, int strategy, char* err, int err_len) {
+  std::unique_ptr<Evaluator> ev;
+  if (engine_kind == 0) {
+    ev.reset(new NullEvaluator());
+  } else {
+    auto* h = new HipEvaluator();
+    ev.reset(h);
+    if (!h->Open(lib_path, weights, num_threads, device)) {
+      if (err && err_len > 0) snprintf(err, err_len, "%s", h->err.c_str());
+      return nullptr;
+    }
+  }
+  return new NNInterface(num_threads, timeout_us, (size_t)cache_size, std::move(ev), (NNInterface::WakeStrategy)strategy);
+}
+void p3host_nn_free(void* nn) { delete (NNInterface*)nn; }
+void p3host_nn_set_num_cache_last_moves(void* nn, int n) { ((NNInterface*)nn)->SetNumCacheLastMoves(n); }
+long p3host_nn_num_inferences(void* nn) { return ((NNInterface*)nn)->num_inferences(); }
+void p3host_nn_register_thread(void* nn, int tid) { ((NNInterface*)nn)->RegisterThread(tid); }
+void p3host_nn_unregister_thread(void* nn, int tid) { ((NNInterface*)nn)->UnregisterThread(tid); }
+// game: a p3host_game_new handle; prob: a p3host_prob_new handle
+void p3host_nn_load_and_get_inference(void* nn, int tid, void* game, int color, void* prob, p3hip_result* out) {
+  *out = ((NNInterface*)nn)->LoadAndGetInference(tid, *(Game*)game, (Color)color, *(Probability*)prob);
+}
+void p3host_nn_load_and_get_ownership(void* nn, int tid, void* game, int color, float* out) {
+  const auto own = ((NNInterface*)nn)->LoadAndGetOwnership(tid, *(Game*)game, (Color)color);
+  std::memcpy(out, own.data(), sizeof(float) * kNumLocs);
+}
+
+// Thread-per-game driver over the handle: thread t plays `moves_per_thread` uniformly random
+// legal moves from the empty board (seed t), evaluating every position through
+// LoadAndGetInference; out[t * stride ...] receives the results of thread t in order.
+// Used to compare the threaded interface with a one-thread interface on the same draws.
+// sequential != 0 runs the same thread bodies one after another (every batch then holds one
+// position and is released by the timeout).
+void p3host_nn_play_threads_ex(void* nn_v, int num_threads, int moves_per_thread, uint64_t seed_base, int sequential,
+                               p3hip_result* out) {
+  NNInterface* nn = (NNInterface*)nn_v;
+  std::vector<std::thread> threads;
+  for (int t = 0; t < num_threads; ++t) {
+    threads.emplace_back([=] {
+      Game game(7.5f, true);
+      Probability prob(seed_base + (uint64_t)t);
+      Color c = kBlack;
+      for (int m = 0; m < moves_per_thread; ++m) {
+        out[(size_t)t * moves_per_thread + m] = nn->LoadAndGetInference(t, game, c, prob);
+        Loc mv = kPassLoc;
+        for (int tries = 0; tries < 64; ++tries) {
+          const int idx = RandRange(prob.prng(), 0, kNumLocs);
+          const Loc l{idx / kBoardLen, idx % kBoardLen};
+          if (game.IsValidMove(l, c)) { mv = l; break; }
+        }
+        game.PlayMove(mv, c);
+        c = Opp(c);
+      }
+      nn->UnregisterThread(t);   // a finished game thread leaves the batch (self_play_thread.cc)
+    });
+    if (sequential) threads.back().join();
+  }
+  if (!sequential)
+    for (auto& th : threads) th.join();
+}
+void p3host_nn_play_threads(void* nn_v, int num_threads, int moves_per_thread, uint64_t seed_base, p3hip_result* out) {
+  p3host_nn_play_threads_ex(nn_v, num_threads, moves_per_thread, seed_base, 0, out);
+}
+
+}  // extern "C"

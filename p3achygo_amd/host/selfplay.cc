@@ -5,16 +5,18 @@
 // raw-policy opening moves, playout-cap randomisation (full search with probability 0.25,
 // otherwise a fast search with per-game k and noise scaling), temperature schedule, Gumbel
 // root search, tree reuse + Reap, pass-alive refresh at moves 200/250/.../400, max_moves,
-// final scoring.  Not restated this round: GoExploit/regret reuse buffer,
-// ForkManager, opening book, handicap games, sel_mult, bias cache, down-bad visit annealing,
-// recorders.
+// final scoring, init-state sampling (handicap games, GoExploit restarts), the fork manager,
+// down-bad visit annealing, sel_mult and the recorders.  Not restated: the
+// opening book (probability 0 in the reference) and the bias cache (off by default).
 //
 // Scheduling is new (the reference runs one OS thread per game and a 400 us batching
 // timeout, nn_interface.cc:279-404): games are resumable state machines (search.h) split in
-// two halves, each half bound to its own engine instance; while the GPU evaluates the leaves
-// of half A, a pool of host threads consumes the results of half B, advances those games to
-// their next leaf and loads the next batch — so every batch holds one leaf of (nearly)
-// every game of its half and the GPU never waits for a timeout.
+// N groups, each group bound to its own engine instance; while the GPU evaluates the leaves
+// of one group, a pool of host threads consumes the results of the others, advances those
+// games to their next leaf and loads the next batch — so every batch holds one leaf of
+// (nearly) every game of its group and the GPU never waits for a timeout.  The reference's
+// blocking thread-per-game NNInterface is kept too (nn_interface.h) for callers written
+// against it.
 #include <dlfcn.h>
 
 #include <functional>
@@ -30,6 +32,7 @@
 
 #include <sys/stat.h>
 
+#include "evaluator.h"
 #include "features.h"
 #include "recorder.h"
 #include "search.h"
@@ -37,72 +40,6 @@
 #include "tf_recorder.h"
 
 namespace p3 {
-
-// ---- evaluator boundary (mirrors nn::Engine, cc/nn/engine/engine.h:22-43) -------------
-struct Evaluator {
-  virtual ~Evaluator() = default;
-  virtual void Load(int slot, const p3hip_features& f) = 0;
-  virtual bool Run() = 0;
-  virtual void Get(int slot, p3hip_result& r) = 0;
-};
-
-// Uniform policy, even outcome, zero score: the reference's NullEngine
-// (cc/mcts/__tests__/search_test.cc:49-65).  Lets the host be tested without a GPU.
-struct NullEvaluator final : Evaluator {
-  void Load(int, const p3hip_features&) override {}
-  bool Run() override { return true; }
-  void Get(int, p3hip_result& r) override {
-    for (int i = 0; i < kNumMoves; ++i) {
-      r.move_logits[i] = 0.0f;
-      r.move_probs[i] = 1.0f / kNumMoves;
-      r.opt_move_probs[i] = 1.0f / kNumMoves;
-    }
-    r.value_probs[0] = r.value_probs[1] = 0.5f;
-    for (int i = 0; i < P3HIP_NUM_SCORE_LOGITS; ++i) r.score_probs[i] = 0.0f;
-    r.score_probs[400] = 1.0f;
-    r.err2_outcome = 0.0f;
-  }
-};
-
-// The HIP engine, bound through its C ABI exactly as a foreign host would bind it.
-struct HipEvaluator final : Evaluator {
-  void* lib = nullptr;
-  p3hip_engine* eng = nullptr;
-  decltype(&p3hip_create) create = nullptr;
-  decltype(&p3hip_destroy) destroy = nullptr;
-  decltype(&p3hip_load_slot) load = nullptr;
-  decltype(&p3hip_run) run = nullptr;
-  decltype(&p3hip_get_slot) get = nullptr;
-  decltype(&p3hip_last_error) last_error = nullptr;
-  decltype(&p3hip_create_error) create_error = nullptr;
-  std::string err;
-
-  bool Open(const char* lib_path, const char* weights, int batch, int device) {
-    lib = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
-    if (!lib) { err = dlerror(); return false; }
-    create = (decltype(create))dlsym(lib, "p3hip_create");
-    destroy = (decltype(destroy))dlsym(lib, "p3hip_destroy");
-    load = (decltype(load))dlsym(lib, "p3hip_load_slot");
-    run = (decltype(run))dlsym(lib, "p3hip_run");
-    get = (decltype(get))dlsym(lib, "p3hip_get_slot");
-    last_error = (decltype(last_error))dlsym(lib, "p3hip_last_error");
-    create_error = (decltype(create_error))dlsym(lib, "p3hip_create_error");
-    if (!create || !destroy || !load || !run || !get) { err = "missing p3hip symbols"; return false; }
-    eng = create(weights, batch, 1, device, 0);
-    if (!eng) { err = create_error ? create_error() : "p3hip_create failed"; return false; }
-    return true;
-  }
-  ~HipEvaluator() override {
-    if (eng) destroy(eng);
-    if (lib) dlclose(lib);
-  }
-  void Load(int slot, const p3hip_features& f) override { load(eng, slot, &f); }
-  bool Run() override {
-    if (run(eng) != 0) { err = last_error(eng); return false; }
-    return true;
-  }
-  void Get(int slot, p3hip_result& r) override { get(eng, slot, &r); }
-};
 
 // ---- one game ----------------------------------------------------------------------------
 // Buffers finished games for both recorders (recorder::GameRecorder, game_recorder.cc:68-175):

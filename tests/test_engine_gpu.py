@@ -162,6 +162,42 @@ def test_selfplay_host_on_hip_engine(built, weight_files):
 
 
 @pytest.mark.gpu
+def test_thread_per_game_nn_interface_on_hip_engine(built, weight_files):
+    """The reference's blocking NNInterface (host/nn_interface.h) over the HIP engine: 32 game
+    threads batched by the infer thread get bit-identical results to the same games run one
+    after another (same symmetry draws), i.e. slots never mix and batching changes nothing."""
+    import ctypes as C
+    from p3achygo_amd import engine, host_api
+    L = host_api.lib()
+    L.p3host_nn_new.restype = C.c_void_p
+    L.p3host_nn_new.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int,
+                                C.c_char_p, C.c_int]
+    L.p3host_nn_free.argtypes = [C.c_void_p]
+    L.p3host_nn_num_inferences.restype = C.c_long
+    L.p3host_nn_num_inferences.argtypes = [C.c_void_p]
+    L.p3host_nn_play_threads_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_void_p]
+    T, M = 32, 10
+    outs, infs = [], []
+    for sequential in (0, 1):
+        err = C.create_string_buffer(512)
+        nn = L.p3host_nn_new(1, engine.LIB_PATH.encode(), weight_files("test_b3c128btl2").encode(), 0, T, 400, 0, 1,
+                             err, 512)
+        assert nn, err.value.decode()
+        out = (engine.Result * (T * M))()
+        L.p3host_nn_play_threads_ex(nn, T, M, 40, sequential, C.byref(out))
+        infs.append(L.p3host_nn_num_inferences(nn))
+        L.p3host_nn_free(nn)
+        words = np.frombuffer(out, dtype=np.uint32).reshape(T * M, -1).copy()
+        assert words.shape[1] == 1892
+        words[:, [1526, 1527, 1891]] = 0        # struct padding (alignas(16) opt_move_probs, tail)
+        outs.append(words)
+    assert np.array_equal(outs[0], outs[1])
+    assert infs[0] < infs[1] == T * M          # threaded run batched the leaves
+    probs = outs[0].view(np.float32)[:, 362:724]
+    assert np.allclose(probs.sum(1), 1.0, atol=1e-3)
+
+
+@pytest.mark.gpu
 def test_eval_match_on_hip_engines(built, weight_files):
     """Config 5 plumbing: two different networks, each behind its own HIP
     engine instance, play evaluation games with the batch parallel search."""

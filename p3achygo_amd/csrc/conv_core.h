@@ -94,6 +94,23 @@ __device__ __forceinline__ float mish_f(float x) {
   return __builtin_fmaf(-2.0f * x, r, x);
 }
 
+// Packed form for the hot epilogues: BN + mish of four values, two per v_pk_* instruction
+// (the compiler's own vectoriser leaves about half of these as scalar ops); exp2 and rcp stay
+// scalar, there is no packed transcendental.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 mish_f2(f32x2 x) {
+  const f32x2 t = x * 1.4426950408889634f;
+  const f32x2 s = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
+  const f32x2 d = __builtin_elementwise_fma(s, s, f32x2{1.0f, 1.0f});
+  const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  return __builtin_elementwise_fma(x * -2.0f, r, x);
+}
+__device__ __forceinline__ h4 bn_mish4(f32x4 v, f32x4 sc, f32x4 sh) {
+  const f32x2 a = mish_f2(__builtin_elementwise_fma(f32x2{v[0], v[1]}, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]}));
+  const f32x2 b = mish_f2(__builtin_elementwise_fma(f32x2{v[2], v[3]}, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]}));
+  return h4{(_Float16)a[0], (_Float16)a[1], (_Float16)b[0], (_Float16)b[1]};
+}
+
 // ---------------------------------------------------------------------------------------
 // Weight ring.  RS = bytes per macro-step (16 KiB for 128-wide panels, 8 KiB for 64-wide);
 // each of the 8 waves copies RS/8 bytes (G = RS/8192 glds of 1 KiB) per macro-step.
@@ -196,7 +213,9 @@ __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
     if (G == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
     else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
   }
+#if !defined(P3_EXP) || !(P3_EXP & 4)
   __builtin_amdgcn_s_barrier();
+#endif
   asm volatile("" ::: "memory");
   if (STAMPS) r.wait_cycles += __builtin_amdgcn_s_memtime() - t0;
   ring_issue(r, smem);
@@ -477,9 +496,8 @@ __device__ __forceinline__ void epilogue_math(EpiOut<NTn>& eo, f32x16 (&acc)[2][
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int mt = k >> 2, g4 = k & 3;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        eo.o[j][k][i] = (_Float16)mish_f(acc[mt][j][g4 * 4 + i] * ep.sc[k][i] + ep.sh[k][i]);
+      const f32x4 v = {acc[mt][j][g4 * 4], acc[mt][j][g4 * 4 + 1], acc[mt][j][g4 * 4 + 2], acc[mt][j][g4 * 4 + 3]};
+      eo.o[j][k] = bn_mish4(v, ep.sc[k], ep.sh[k]);
     }
 }
 
@@ -577,11 +595,9 @@ __device__ __forceinline__ void stage_store(char* smem, const XRegs<G>& xr, int 
     const h8 v = xr.v[i];
     h8 o;
     if (PRE) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = (_Float16)mish_f((float)v[e] * s0[e] + t0[e]);
-        o[e + 4] = (_Float16)mish_f((float)v[e + 4] * s1[e] + t1[e]);
-      }
+      const h4 lo = bn_mish4(f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, s0, t0);
+      const h4 hi = bn_mish4(f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]}, s1, t1);
+      o = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     } else {
       o = v;
     }
@@ -606,13 +622,9 @@ __device__ __forceinline__ void stage_math(XRegs<G>& xr, int cblk0, const float*
 #pragma unroll
   for (int i = 0; i < kXLoads; ++i) {
     const h8 v = xr.v[i];
-    h8 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      o[e] = (_Float16)mish_f((float)v[e] * s0[e] + t0[e]);
-      o[e + 4] = (_Float16)mish_f((float)v[e + 4] * s1[e] + t1[e]);
-    }
-    xr.v[i] = o;
+    const h4 lo = bn_mish4(f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, s0, t0);
+    const h4 hi = bn_mish4(f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]}, s1, t1);
+    xr.v[i] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   }
 }
 

@@ -49,6 +49,13 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
   ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
   if (STAMPS) ring.dbg = a.dbg;
   lds_barrier();
+#if (P3_EXP & 64)
+  {   // stagger experiment: workgroup i starts (i % 8) * 3000 cycles late
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long d = (unsigned long long)(blockIdx.x & 7) * 3000ull;
+    while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
 
   static_assert(C / CB == 2, "two input slices / two output passes");
   XRegs<G> xr;
@@ -63,7 +70,10 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
     stage_store<G, false>(smem, xr, 0, nullptr, nullptr);
     acc16_zero<NT>(acc);
     stage_load<G>(xr, a.x, C, pos0, a.npos, G::NCH);
-    ring_note_xloads(ring);
+    // younger than the glds the next two acquires wait for: these 12 loads and, after the
+    // first position, the 12 output stores of the previous position's last pass (the 12
+    // loads of the next-position prefetch issued before them are already consumed)
+    ring_note_inflight(ring, npos_done == 0 ? 12 : 24);
     P3_STAMP(1);
     conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
     P3_STAMP(2);
@@ -109,26 +119,21 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
         // the loaded values, i.e. the same exposed latency plus scratch traffic)
         residual_addr16<G, CB, NT>(tr, CB, pos0, a.npos, 0);
         residual_load16<NT>(tr, a.t);
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[ct][j][i] += (float)tr.rv[j][ct][i];
+        residual_add16<NT>(acc, tr);
         if (r == 0) epilogue_store16<false, NT>(acc, tr, a.t);
         epilogue_layer16<G, CB, NT>(smem, acc, a.scale[3 + 2 * r], a.shift[3 + 2 * r]);
       }
     }
     // ---- expand 1x1 (CB -> C) + residual, straight to HBM.  The residual of each output
-    // pass is loaded before that pass's MFMAs (24 loads/lane); in pass 1 the 24 stores of
-    // pass 0 are in flight as well ------------------------------------------------------
+    // pass is loaded before that pass's MFMAs (12 sixteen-byte loads/lane); in pass 1 the 12
+    // stores of pass 0 are in flight as well ------------------------------------------------------
     P3_STAMP(12);
 #pragma unroll
     for (int cp = 0; cp < C / CB; ++cp) {   // fully unrolled: xr must not look live across passes
       ResRegs16<NT> rr;
       residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, cp * CB);
       residual_load16<NT>(rr, a.x);
-      ring_note_inflight(ring, cp == 0 ? 24 : 48);
+      ring_note_inflight(ring, cp == 0 ? 12 : 24);
       acc16_zero<NT>(acc);
       conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
       P3_STAMP(13 + 2 * cp);

@@ -118,12 +118,17 @@ template <int RS>
 struct Ring {
   static constexpr int G = RS / 8192;
   static_assert(G == 1 || G == 2, "ring slot size");
-  const char* gbase;   // packed stream (global), nms_total macro-steps of RS bytes
-  int nms_total;
+  // Scalar state only, kept as running pointers and rotating slot addresses so that one
+  // acquire costs a handful of SALU instructions (an index-based ring recomputed two 64-bit
+  // stream addresses, three LDS addresses and three wrap-arounds per acquire: ~100 scalar
+  // instructions at the head of every unrolled K-loop body, stalling both waves of a SIMD
+  // at the same time).
+  const char* gcur;    // this wave's piece of the next macro-step to prefetch (lane offset excluded)
+  const char* gbeg;    // ... of macro-step 0
+  const char* gend;    // ... one past the last macro-step (the stream is circular)
+  uint32_t fill[kRingSlots];  // LDS address of this wave's piece in the slot the next, next+1, ... prefetch fills
+  uint32_t use[kRingSlots];   // LDS offset of the slot the next, next+1, ... acquire returns
   uint32_t lds_base;   // byte offset of the ring inside the dynamic LDS array
-  int pf;              // next stream macro-step to prefetch (circular)
-  int pf_slot;
-  int slot;            // ring slot of the next macro-step to consume
   int tol;             // acquires left that must tolerate `extra` younger register loads/stores
   int extra;           // 12, 24, 36 or 48 (see ring_note_inflight)
   unsigned long long wait_cycles;  // diagnostic builds: cycles spent in ring_acquire waits
@@ -134,29 +139,41 @@ struct Ring {
 // 16-byte global loads (see stage_load) while the ring keeps streaming.
 constexpr int kXLoads = 12;
 
+template <int N>
+__device__ __forceinline__ void rotate_left(uint32_t (&v)[N]) {
+  const uint32_t t = v[0];
+#pragma unroll
+  for (int i = 0; i + 1 < N; ++i) v[i] = v[i + 1];
+  v[N - 1] = t;
+}
+
 template <int RS>
 __device__ __forceinline__ void ring_issue(Ring<RS>& r, char* smem) {
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const char* gp = r.gbase + (size_t)r.pf * RS + wid * (RS / 8) + lane * 16;
-  char* lp = smem + r.lds_base + r.pf_slot * RS + wid * (RS / 8);
+  const uint32_t lane16 = (threadIdx.x & 63) * 16;
+  const char* gp = r.gcur + lane16;      // uniform base + 32-bit lane offset
+  char* lp = smem + r.fill[0];
 #pragma unroll
   for (int i = 0; i < Ring<RS>::G; ++i)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + i * 1024),
                                      (__attribute__((address_space(3))) void*)(lp + i * 1024), 16, 0, 0);
-  r.pf = (r.pf + 1 == r.nms_total) ? 0 : r.pf + 1;
-  r.pf_slot = (r.pf_slot + 1 == kRingSlots) ? 0 : r.pf_slot + 1;
+  r.gcur += RS;
+  if (r.gcur == r.gend) r.gcur = r.gbeg;
+  rotate_left(r.fill);
 }
 
 template <int RS>
 __device__ __forceinline__ void ring_init(Ring<RS>& r, char* smem, const void* gbase,
                                           int nms_total, uint32_t lds_base) {
-  r.gbase = (const char*)gbase;
-  r.nms_total = nms_total;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  r.gbeg = (const char*)gbase + wid * (RS / 8);
+  r.gend = r.gbeg + (size_t)nms_total * RS;
+  r.gcur = r.gbeg;
   r.lds_base = lds_base;
-  r.pf = 0;
-  r.pf_slot = 0;
-  r.slot = 0;
+#pragma unroll
+  for (int i = 0; i < kRingSlots; ++i) {
+    r.use[i] = lds_base + i * RS;
+    r.fill[i] = lds_base + i * RS + wid * (RS / 8);
+  }
   r.tol = 0;
   r.extra = 0;
   r.wait_cycles = 0;
@@ -187,8 +204,8 @@ __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
   unsigned long long t0 = 0;
   if (STAMPS) {
     if (r.dbg & 1) {  // timing experiment: no synchronisation at all (results are garbage)
-      uint32_t off = r.lds_base + r.slot * RS;
-      r.slot = (r.slot + 1 == kRingSlots) ? 0 : r.slot + 1;
+      const uint32_t off = r.use[0];
+      rotate_left(r.use);
       return off;
     }
     t0 = __builtin_amdgcn_s_memtime();
@@ -219,8 +236,8 @@ __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
   asm volatile("" ::: "memory");
   if (STAMPS) r.wait_cycles += __builtin_amdgcn_s_memtime() - t0;
   ring_issue(r, smem);
-  uint32_t off = r.lds_base + r.slot * RS;
-  r.slot = (r.slot + 1 == kRingSlots) ? 0 : r.slot + 1;
+  const uint32_t off = r.use[0];
+  rotate_left(r.use);
   return off;
 }
 

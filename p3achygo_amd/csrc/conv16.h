@@ -88,6 +88,8 @@ __device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS)>&
   using T = Tiling16<G, COUT_PASS>;
   static_assert(NTn == T::NT, "accumulator shape");
   static_assert(G::CB % 32 == 0 && NTAPS_PAD == KW * KW, "k32 steps, unpadded taps");
+  if constexpr ((P3_EXP & 128) != 0 && KW == 1) return;   // timing experiment: no 1x1 segments
+  if constexpr ((P3_EXP & 256) != 0 && KW == 3) return;   // timing experiment: no 3x3 segments
   constexpr int NT = T::NT, NB = NT / 2;
   constexpr int NQ = G::CB / 32;                   // k32-steps per tap
   constexpr int U = KW * NQ;                       // unrolled body: one kernel row

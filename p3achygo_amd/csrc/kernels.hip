@@ -128,20 +128,29 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
     // pass is loaded before that pass's MFMAs (12 sixteen-byte loads/lane); in pass 1 the 12
     // stores of pass 0 are in flight as well ------------------------------------------------------
     P3_STAMP(12);
-#pragma unroll
-    for (int cp = 0; cp < C / CB; ++cp) {   // fully unrolled: xr must not look live across passes
-      ResRegs16<NT> rr;
-      residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, cp * CB);
-      residual_load16<NT>(rr, a.x);
-      ring_note_inflight(ring, cp == 0 ? 12 : 24);
+    {
+      // Pass 1's residual is requested before pass 0's output stores go out: vmcnt retires in
+      // issue order, so loads issued behind the stores would also wait for the stores' acks.
+      ResRegs16<NT> rr0, rr1;
+      residual_addr16<G, CB, NT>(rr0, C, pos0, a.npos, 0);
+      residual_load16<NT>(rr0, a.x);
+      ring_note_inflight(ring, 12);
       acc16_zero<NT>(acc);
       conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
-      P3_STAMP(13 + 2 * cp);
+      P3_STAMP(13);
+      residual_addr16<G, CB, NT>(rr1, C, pos0, a.npos, CB);
+      residual_load16<NT>(rr1, a.x);
+      epilogue_store16<true, NT>(acc, rr0, a.x);
+      P3_STAMP(14);
+      ring_note_inflight(ring, 24);
+      acc16_zero<NT>(acc);
+      conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
+      P3_STAMP(15);
       // next position's first slice: issued once the last K loop of this position is over
       // (no fragment registers live), lands under the residual epilogue's stores
-      if (cp == C / CB - 1) stage_load<G>(xr, a.x, C, pos_next, a.npos, 0);
-      epilogue_store16<true, NT>(acc, rr, a.x);
-      P3_STAMP(14 + 2 * cp);
+      stage_load<G>(xr, a.x, C, pos_next, a.npos, 0);
+      epilogue_store16<true, NT>(acc, rr1, a.x);
+      P3_STAMP(16);
     }
     stage_math<G>(xr, 0, a.scale[0], a.shift[0]);   // next position's slice 0, before the barrier
     lds_barrier();

@@ -49,6 +49,12 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
   ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
   if (STAMPS) ring.dbg = a.dbg;
   lds_barrier();
+#if (P3_EXP & 512)
+  if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger half
+#endif
+#if (P3_EXP & 1024)
+  if (threadIdx.x < 256) __builtin_amdgcn_s_setprio(1);    // experiment: ... for the older half
+#endif
 #if (P3_EXP & 64)
   {   // stagger experiment: workgroup i starts (i % 8) * 3000 cycles late
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();

@@ -662,12 +662,19 @@ __device__ __forceinline__ void act_zero(char* smem) {
 
 // Epilogue B: out[c][loc] = acc + residual (read from the same place) -> fp16 global, in
 // the channel-blocked layout; cofs = first channel of this cout pass.  Split in two so the
-// 24 residual loads can be issued before the conv segment whose result they are added to
-// (their latency hides under its MFMAs): residual_load, then epilogue_residual_store.
+// Residual loads can be issued before the conv segment whose result they are added to
+// (their latency hides under its MFMAs): residual_load, then epilogue_store.
+//
+// A lane's accumulator quad (mt, g4) is one 8-byte HALF of the 16-byte [8 channels] piece of
+// its board row; the other half sits in the partner lane 32 lanes away.  One
+// v_permlane32_swap per dword turns "my half of channel blocks k and k+1" into "the whole piece
+// of ONE block": block k in lanes 0-31, block k+1 in lanes 32-63.  Loads and stores then move
+// 16 bytes per lane (half the instructions; the store tail is issue-bound) and a wave
+// instruction covers two contiguous 512-byte runs.
 template <class G, int COUT_PASS, int NTn>
 struct ResRegs {
-  h4 rv[NTn][8];
-  size_t base[NTn];
+  h8 rv[NTn][4];       // piece of this lane's row, channel block 2*kp + (lane >> 5)
+  uint32_t base[NTn];  // element offset of that piece for kp = 0
   bool ok[NTn];
 };
 
@@ -679,7 +686,7 @@ __device__ __forceinline__ void residual_addr(ResRegs<G, COUT_PASS, NTn>& rr, in
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lg = wid / T::CG;
   const int lr = lane & 31, h = lane >> 5;
-  const int c0 = cofs + cg_of<G, COUT_PASS>() * 64 + h * 4;   // channel of (mt=0, g4=0)
+  const int cblk = ((cofs + cg_of<G, COUT_PASS>() * 64) >> 3) + h;   // this lane's block of pair 0
 #pragma unroll
   for (int j = 0; j < NTn; ++j) {
     const int t = lg + j * T::LG;
@@ -689,19 +696,57 @@ __device__ __forceinline__ void residual_addr(ResRegs<G, COUT_PASS, NTn>& rr, in
     rr.ok[j] = row_valid<G::S>(tt * 32 + lr, loc) && (pos0 + p < npos) && (t < G::NT_TOTAL);
     if (!rr.ok[j]) loc = 0;
     const int pp = (pos0 + p < npos) ? pos0 + p : npos - 1;
-    rr.base[j] = ((size_t)pp * (C / 8) + (c0 >> 3)) * (kNLoc * 8) + loc * 8 + h * 4;
+    rr.base[j] = (uint32_t)((pp * (C / 8) + cblk) * (kNLoc * 8) + loc * 8);
   }
 }
 
-// Issues exactly NTn*8 = 24 loads per lane (invalid rows read a valid dummy address).
+// Issues exactly NTn*4 sixteen-byte loads per lane (invalid rows read a valid dummy address).
 template <class G, int COUT_PASS, int NTn>
 __device__ __forceinline__ void residual_load(ResRegs<G, COUT_PASS, NTn>& rr,
                                               const _Float16* __restrict__ x) {
 #pragma unroll
   for (int j = 0; j < NTn; ++j)
 #pragma unroll
-    for (int k = 0; k < 8; ++k)   // k = mt*4 + g4: channel block c0/8 + k
-      rr.rv[j][k] = *(const h4*)(x + rr.base[j] + (size_t)k * (kNLoc * 8));
+    for (int kp = 0; kp < 4; ++kp)   // channel blocks 2*kp, 2*kp + 1
+      rr.rv[j][kp] = *(const h8*)((const char*)x + (size_t)kp * (2 * kNLoc * 8 * 2) + (uint32_t)(rr.base[j] * 2u));
+}
+
+// (x = my half of block k, y = my half of block k+1)  <->  (low, high half of my own block's piece)
+__device__ __forceinline__ void half_swap32(h4& x, h4& y) {
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  u2 xu = __builtin_bit_cast(u2, x), yu = __builtin_bit_cast(u2, y);
+  auto s0 = __builtin_amdgcn_permlane32_swap(xu[0], yu[0], false, false);
+  auto s1 = __builtin_amdgcn_permlane32_swap(xu[1], yu[1], false, false);
+  xu[0] = s0[0]; yu[0] = s0[1];
+  xu[1] = s1[0]; yu[1] = s1[1];
+  x = __builtin_bit_cast(h4, xu);
+  y = __builtin_bit_cast(h4, yu);
+}
+
+// this lane's residual values for channel blocks k = 2*kp (r0) and 2*kp + 1 (r1) of tile j
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void residual_unpack(const ResRegs<G, COUT_PASS, NTn>& rr, int j, int kp, h4& r0, h4& r1) {
+  const h8 v = rr.rv[j][kp];
+  r0 = h4{v[0], v[1], v[2], v[3]};
+  r1 = h4{v[4], v[5], v[6], v[7]};
+  half_swap32(r0, r1);
+}
+
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void residual_add(f32x16 (&acc)[2][NTn], const ResRegs<G, COUT_PASS, NTn>& rr) {
+#pragma unroll
+  for (int j = 0; j < NTn; ++j)
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) {
+      h4 r0, r1;
+      residual_unpack<G, COUT_PASS, NTn>(rr, j, kp, r0, r1);
+      const int k0 = 2 * kp, k1 = 2 * kp + 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[k0 >> 2][j][(k0 & 3) * 4 + i] += (float)r0[i];
+        acc[k1 >> 2][j][(k1 & 3) * 4 + i] += (float)r1[i];
+      }
+    }
 }
 
 template <class G, int COUT_PASS, bool RESIDUAL, int NTn>
@@ -711,16 +756,21 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[2][NTn],
 #pragma unroll
   for (int j = 0; j < NTn; ++j)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int mt = k >> 2, g4 = k & 3;
-      h4 o;
+    for (int kp = 0; kp < 4; ++kp) {
+      const int k0 = 2 * kp, k1 = 2 * kp + 1;
+      h4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0};
+      if (RESIDUAL) residual_unpack<G, COUT_PASS, NTn>(rr, j, kp, r0, r1);
+      h4 o0, o1;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float v = acc[mt][j][g4 * 4 + i];
-        if (RESIDUAL) v += (float)rr.rv[j][k][i];
-        o[i] = (_Float16)v;
+        float v0 = acc[k0 >> 2][j][(k0 & 3) * 4 + i], v1 = acc[k1 >> 2][j][(k1 & 3) * 4 + i];
+        if (RESIDUAL) { v0 += (float)r0[i]; v1 += (float)r1[i]; }
+        o0[i] = (_Float16)v0;
+        o1[i] = (_Float16)v1;
       }
-      if (rr.ok[j]) *(h4*)(x + rr.base[j] + (size_t)k * (kNLoc * 8)) = o;
+      half_swap32(o0, o1);   // every lane takes part
+      const h8 piece = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+      if (rr.ok[j]) *(h8*)((char*)x + (size_t)kp * (2 * kNLoc * 8 * 2) + (uint32_t)(rr.base[j] * 2u)) = piece;
     }
 }
 

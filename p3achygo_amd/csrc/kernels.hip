@@ -338,7 +338,8 @@ __global__ void __launch_bounds__(kWG, 2) k_conv1x1(Conv1x1Args a) {
         pending_stores = 0;
         conv_segment<G, CP, 1, 1>(ring, smem, acc);
       }
-      pending_stores = (EPI == 2) ? 0 : 24;
+      static_assert(EPI == 2 || T::NT == 3, "vmcnt bookkeeping: 12 sixteen-byte stores per pass");
+      pending_stores = (EPI == 2) ? 0 : 12;
       if (EPI == 1) {
         epilogue_to_global<G, CP, true>(acc, a.out16, COUT, pos0, a.npos, cp * CP);
       } else if (EPI == 0) {
@@ -443,19 +444,15 @@ __global__ void __launch_bounds__(kWG, 2) k_lconv(LConvArgs a) {
         residual_addr<G, CP, T::NT>(rr, COUT, pos0, a.npos, cp * CP);
         if (RES) {
           residual_load<G, CP, T::NT>(rr, a.out);
-#pragma unroll
-          for (int j = 0; j < T::NT; ++j)
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) acc[k >> 2][j][(k & 3) * 4 + i] += (float)rr.rv[j][k][i];
+          residual_add<G, CP, T::NT>(acc, rr);
         }
+        static_assert(T::NT == 3, "vmcnt bookkeeping: 12 sixteen-byte stores per output");
         epilogue_store<G, CP, false, T::NT>(acc, rr, a.out);    // raw y
         activate();
         epilogue_store<G, CP, false, T::NT>(acc, rr, a.out2);   // the consumer's input, activated once here
-        pending_stores = 36;   // 48 stores are in flight; under-noting only makes the next acquires stricter
-      } else {
         pending_stores = 24;
+      } else {
+        pending_stores = 12;
         if (ACT) activate();
         epilogue_to_global<G, CP, RES>(acc, a.out, COUT, pos0, a.npos, cp * CP);
       }

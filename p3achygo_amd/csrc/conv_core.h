@@ -181,6 +181,14 @@ __device__ __forceinline__ void ring_init(Ring<RS>& r, char* smem, const void* g
   for (int i = 0; i < kRingDepth; ++i) ring_issue(r, smem);
 }
 
+// The next wrap of the prefetch pointer goes to the start of another stream (the caller sets
+// gend once the wrap has happened).
+template <int RS>
+__device__ __forceinline__ void ring_retarget(Ring<RS>& r, const void* gbase) {
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  r.gbeg = (const char*)gbase + wid * (RS / 8);
+}
+
 // Makes the next macro-step readable and returns its LDS byte offset.
 // Invariant on entry: this wave has exactly D*G glds in flight (macro-steps m..m+D-1),
 // possibly followed by younger ordinary loads/stores (which only make the wait stricter).

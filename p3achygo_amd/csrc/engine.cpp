@@ -369,18 +369,34 @@ int grid_for(const p3hip_engine* e, int npos, int npos_per_wg) {
   return wgs < e->n_cu ? wgs : e->n_cu;
 }
 
-p3::BlockArgs block_args(p3hip_engine* e, const BlockPlan& bp, int npos) {
+// Arguments of one k_block launch over the consecutive fused blocks [first, first + count).
+p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
   p3::BlockArgs a{};
   a.x = e->d_x;
   a.t = e->d_t;
   a.npos = npos;
-  a.wstream = e->d_arena + bp.stream_off;
-  a.nms_total = bp.nms;
-  for (int j = 0; j < p3::kMaxBlockLayers; ++j) {
-    a.scale[j] = e->dev<float>(bp.bn[j].scale_off);
-    a.shift[j] = e->dev<float>(bp.bn[j].shift_off);
+  a.nblk = count;
+  for (int b = 0; b < count; ++b) {
+    const BlockPlan& bp = e->blocks[first + b];
+    a.blk[b].wstream = e->d_arena + bp.stream_off;
+    a.blk[b].nms_total = bp.nms;
+    for (int j = 0; j < p3::kMaxBlockLayers; ++j) {
+      a.blk[b].scale[j] = e->dev<float>(bp.bn[j].scale_off);
+      a.blk[b].shift[j] = e->dev<float>(bp.bn[j].shift_off);
+    }
   }
   return a;
+}
+
+// Number of blocks the launch starting at block `first` covers: consecutive blocks of the fused
+// kernel's kind, at most kMaxFuse (1 when P3HIP_NO_FUSE is set: one launch per block).
+int fused_run(const p3hip_engine* e, size_t first) {
+  const int kind = e->blocks[first].kind;
+  if (kind != 0 && kind != 1) return 0;
+  static const bool no_fuse = getenv("P3HIP_NO_FUSE") != nullptr;
+  int n = 1;
+  while (!no_fuse && n < p3::kMaxFuse && first + n < e->blocks.size() && e->blocks[first + n].kind == kind) ++n;
+  return n;
 }
 
 // Enqueues the whole forward pass for `npos` dense positions already in d_feats.
@@ -396,7 +412,8 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
     a.game_w = e->dev<float>(e->game_w_off); a.game_b = e->dev<float>(e->game_b_off);
     if (!e->check(p3::launch_init(C, a, grid_for(e, npos, 1), s), "launch k_init")) return false;
   }
-  for (const BlockPlan& bp : e->blocks) {
+  for (size_t bi = 0; bi < e->blocks.size(); ++bi) {
+    const BlockPlan& bp = e->blocks[bi];
     if (bp.kind == 3) {
       p3::Conv1x1Args c0{};
       c0.in = e->d_x; c0.out16 = e->d_t; c0.npos = npos;
@@ -427,11 +444,13 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
         if (!e->check(p3::launch_lconv(lp.kw, lp.cin, lp.cout, a, e->n_cu, s), "launch k_lconv")) return false;
       }
     } else {
-      p3::BlockArgs a = block_args(e, bp, npos);
+      const int run = fused_run(e, bi);
+      p3::BlockArgs a = block_args(e, bi, run, npos);
       const bool timed = e->time_blocks && 2 * e->timed_blocks + 1 < (int)e->blk_ev.size();
       if (timed) hipEventRecord(e->blk_ev[2 * e->timed_blocks], s);
       if (!e->check(p3::launch_block(C, bp.kind, wf.inner, a, grid_for(e, npos, npw), s), "launch k_block")) return false;
       if (timed) hipEventRecord(e->blk_ev[2 * e->timed_blocks++ + 1], s);
+      bi += run - 1;
     }
   }
   {
@@ -657,7 +676,7 @@ int p3hip_debug_block_stamps(p3hip_engine* e, int n_positions, unsigned long lon
   unsigned long long* d = nullptr;
   if (!e->check(hipMalloc((void**)&d, n * 8), "hipMalloc stamps")) return 1;
   hipMemsetAsync(d, 0, n * 8, e->stream);
-  p3::BlockArgs a = block_args(e, *bp, n_positions);
+  p3::BlockArgs a = block_args(e, (size_t)(bp - e->blocks.data()), 1, n_positions);
   a.stamps = d;
   a.dbg = getenv("P3HIP_DBG") ? atoi(getenv("P3HIP_DBG")) : 0;
   bool ok = e->check(p3::launch_block_stamps(a, grid, e->stream), "launch stamps") &&
@@ -701,8 +720,10 @@ double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
   }
   const double n3 = (wf.btype == 0) ? wf.inner : 4;
   // every conv the block kernel executes: the inner 3x3s plus the 1x1 reduce and expand
+  // a launch covers `nfused / launches-per-forward` blocks on average
+  const double blocks_per_launch = launches ? (double)nfused * iters / launches : 1.0;
   if (flops_per_launch)
-    *flops_per_launch = 2.0 * n_positions * kNLoc * (n3 * 9.0 * wf.Cb * wf.Cb + 2.0 * wf.C * wf.Cb);
+    *flops_per_launch = blocks_per_launch * 2.0 * n_positions * kNLoc * (n3 * 9.0 * wf.Cb * wf.Cb + 2.0 * wf.C * wf.Cb);
   if (kernel_name) *kernel_name = p3::block_kernel_name(wf.C, bp->kind, wf.inner);
   return launches ? total_ms / launches : -1.0;
 }

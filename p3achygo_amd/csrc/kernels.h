@@ -24,14 +24,22 @@ constexpr int kOutStride = 3416;
 
 constexpr int kMaxBlockLayers = 8;
 
+// One launch runs `nblk` consecutive residual blocks of the same shape: positions are private
+// to a workgroup, so block b+1 of a position only needs block b of the SAME workgroup — no
+// grid-wide dependency, just the launch boundaries (ramp, tail, cold ring) saved.
+constexpr int kMaxFuse = 6;
+struct BlockParams {
+  const void* wstream;  // packed weight stream of the block
+  int nms_total;        // its length in macro-steps
+  const float* scale[kMaxBlockLayers];  // folded BN of conv j's prologue
+  const float* shift[kMaxBlockLayers];
+};
 struct BlockArgs {
   _Float16* x;          // residual stream, updated in place
   _Float16* t;          // nbt: scratch for the inner residual stream [pos][CB/8][361][8]
   int npos;
-  const void* wstream;  // packed weight stream of this block
-  int nms_total;        // its length in 8 KiB macro-steps
-  const float* scale[kMaxBlockLayers];  // folded BN of conv j's prologue
-  const float* shift[kMaxBlockLayers];
+  int nblk;
+  BlockParams blk[kMaxFuse];
   unsigned long long* stamps;  // diagnostic build only
   int dbg;                     // diagnostic build only
 };

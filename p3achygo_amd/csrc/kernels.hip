@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
 
   act_zero<G>(smem);
   Ring<T::RS> ring;
-  ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
+  ring_init(ring, smem, a.blk[0].wstream, a.blk[0].nms_total, kRingOff);
   if (STAMPS) ring.dbg = a.dbg;
   lds_barrier();
 #if (P3_EXP & 512)
@@ -64,12 +64,26 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
 #endif
 
   static_assert(C / CB == 2, "two input slices / two output passes");
+#pragma unroll 1
+  for (int blk = 0; blk < a.nblk; ++blk) {
+  const BlockParams& bp = a.blk[blk];
+  if (blk > 0) {
+    // Block boundary: this workgroup's own stores of the previous block (other waves wrote
+    // the pieces this wave stages) must have been acknowledged before they are read back.
+    ring_drain();
+    __builtin_amdgcn_s_barrier();
+    ring.gend = ring.gbeg + (size_t)bp.nms_total * T::RS;   // gbeg was switched during the last position
+  }
   XRegs<G> xr;
   stage_load<G>(xr, a.x, C, blockIdx.x * NPOS, a.npos, 0);
-  stage_math<G>(xr, 0, a.scale[0], a.shift[0]);
+  stage_math<G>(xr, 0, bp.scale[0], bp.shift[0]);
   int npos_done = 0;
   for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS, ++npos_done) {
     f32x4 acc[4][NT];
+    const int pos_next = pos0 + gridDim.x * NPOS;
+    // last position of a block that is not the last: the weight prefetch wraps into the next
+    // block's stream instead of this block's start
+    if (pos_next >= a.npos && blk + 1 < a.nblk) ring_retarget(ring, a.blk[blk + 1].wstream);
     P3_STAMP(0);
     // ---- reduce 1x1 (C -> CB), prologue bn0+mish applied to the fetched slice in
     // registers; slice 1 is fetched under the slice-0 MFMAs -------------------------------
@@ -83,17 +97,16 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
     P3_STAMP(1);
     conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
     P3_STAMP(2);
-    stage_math<G>(xr, G::NCH, a.scale[0], a.shift[0]);
+    stage_math<G>(xr, G::NCH, bp.scale[0], bp.shift[0]);
     lds_barrier();
     stage_store<G, false>(smem, xr, G::NCH, nullptr, nullptr);
     P3_STAMP(3);
     conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
     P3_STAMP(4);
-    const int pos_next = pos0 + gridDim.x * NPOS;
     if (KIND == 0) {
 #pragma unroll
       for (int j = 1; j <= L; ++j) {
-        epilogue_layer16<G, CB, NT>(smem, acc, a.scale[j], a.shift[j]);
+        epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[j], bp.shift[j]);
         acc16_zero<NT>(acc);
         P3_STAMP(3 + 2 * j);
         conv_segment16<G, CB, 3, 9, STAMPS>(ring, smem, acc);
@@ -103,7 +116,7 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
           a.stamps[((blockIdx.x * 8 + w_) * 4 + npos_done) * 32 + 20 + j] = ring.wait_cycles;
         }
       }
-      epilogue_layer16<G, CB, NT>(smem, acc, a.scale[L + 1], a.shift[L + 1]);
+      epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[L + 1], bp.shift[L + 1]);
       P3_STAMP(11);
     } else {
       // nbt: the raw inner residual stream t is parked in HBM scratch (fp16, as the reference's
@@ -113,12 +126,12 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
       ResRegs16<NT> tr;
       residual_addr16<G, CB, NT>(tr, CB, pos0, a.npos, 0);
       epilogue_store16<false, NT>(acc, tr, a.t);
-      epilogue_layer16<G, CB, NT>(smem, acc, a.scale[1], a.shift[1]);
+      epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[1], bp.shift[1]);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         acc16_zero<NT>(acc);
         conv_segment16<G, CB, 3, 9, STAMPS>(ring, smem, acc);
-        epilogue_layer16<G, CB, NT>(smem, acc, a.scale[2 + 2 * r], a.shift[2 + 2 * r]);
+        epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[2 + 2 * r], bp.shift[2 + 2 * r]);
         acc16_zero<NT>(acc);
         conv_segment16<G, CB, 3, 9, STAMPS>(ring, smem, acc);
         // t is fetched after the K loop: holding it across the 3x3 loop costs more (spills of
@@ -127,7 +140,7 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
         residual_load16<NT>(tr, a.t);
         residual_add16<NT>(acc, tr);
         if (r == 0) epilogue_store16<false, NT>(acc, tr, a.t);
-        epilogue_layer16<G, CB, NT>(smem, acc, a.scale[3 + 2 * r], a.shift[3 + 2 * r]);
+        epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[3 + 2 * r], bp.shift[3 + 2 * r]);
       }
     }
     // ---- expand 1x1 (CB -> C) + residual, straight to HBM.  The residual of each output
@@ -158,10 +171,11 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
       epilogue_store16<true, NT>(acc, rr1, a.x);
       P3_STAMP(16);
     }
-    stage_math<G>(xr, 0, a.scale[0], a.shift[0]);   // next position's slice 0, before the barrier
+    stage_math<G>(xr, 0, bp.scale[0], bp.shift[0]);   // next position's slice 0, before the barrier
     lds_barrier();
     P3_STAMP(17);
   }
+  }   // blocks
   ring_drain();
 }
 

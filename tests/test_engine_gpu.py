@@ -5,6 +5,7 @@ Tolerance (fp16 trunk with fp32 accumulation vs fp32/float64 reference), stated 
 SURVEY.md §8c and tightened after measurement: logits |d| <= 2e-2 abs, probabilities
 <= 2e-3 abs, argmax of the policy identical on the fixture set.
 """
+import os
 import threading
 
 import numpy as np
@@ -159,6 +160,45 @@ def test_selfplay_host_on_hip_engine(built, weight_files):
     mv, bs, ws, ev = host_api.selfplay_one_game(weight_files("test_b3c128btl2"), 8, 4, 80, seed=9)
     mv2, *_ = host_api.selfplay_one_game(weight_files("test_b3c128btl2"), 8, 4, 80, seed=9)
     assert len(mv) > 10 and np.array_equal(mv, mv2)   # deterministic on the GPU too
+
+
+_FUSE_CHILD = r"""
+import sys, hashlib, tempfile, os
+sys.path.insert(0, %r)
+import numpy as np
+from p3achygo_amd import engine, features, netspec
+for name, batch in (("b12c256btl3", 300), ("b8c128nbt", 70), ("b12c256btl3", 5)):
+    cfg = netspec.CONFIGS[name]
+    path = os.path.join(tempfile.mkdtemp(), "n.p3w")
+    netspec.save_p3w(path, cfg, netspec.generate_weights(cfg, randomize=True))
+    pos = features.random_positions(batch, seed=3, n_games=7)
+    eng = engine.HipEngine(path, batch)
+    eng.load_all(pos); eng.RunInference()
+    raw = np.stack([eng.get_raw(i) for i in range(batch)])
+    print(name, batch, hashlib.sha256(raw.tobytes()).hexdigest())
+    eng.close()
+"""
+
+
+@pytest.mark.gpu
+def test_fused_block_launches_equal_one_launch_per_block(built):
+    """One k_block launch runs up to six consecutive residual blocks (workgroups own their
+    positions, so there is no grid-wide dependency between blocks).  Same arithmetic, same
+    order: the outputs must be bit-identical to one launch per block (P3HIP_NO_FUSE), with
+    several positions per workgroup (300), with two per workgroup slot (C=128, 70) and with
+    fewer positions than workgroups (5)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for no_fuse in (False, True):
+        env = dict(os.environ)
+        env.pop("P3HIP_NO_FUSE", None)
+        if no_fuse:
+            env["P3HIP_NO_FUSE"] = "1"
+        r = subprocess.run([sys.executable, "-c", _FUSE_CHILD % root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and outs[0].count("\n") == 3
 
 
 @pytest.mark.gpu

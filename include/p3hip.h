@@ -84,8 +84,9 @@ typedef struct p3hip_engine p3hip_engine;
 
 /* p3hip_create flags */
 #define P3HIP_FLAG_NONE 0u
-#define P3HIP_FLAG_NO_GRAPH 1u      /* reserved: kernels are always launched eagerly (17 launches of
-                                       0.05-0.4 ms per forward pass; launch cost is hidden) */
+#define P3HIP_FLAG_NO_GRAPH 1u      /* reserved: kernels are always launched eagerly (11 launches of
+                                       0.07-1.5 ms per forward pass of b12c256btl3; launch cost is
+                                       hidden behind the running kernels) */
 #define P3HIP_FLAG_RUN_ALL_SLOTS 2u /* always run the full static batch (TRT behaviour,
                                        trt_engine.cc:238-304); default compacts to loaded slots */
 

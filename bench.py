@@ -135,10 +135,11 @@ def main():
         from p3achygo_amd import host_api
         cpus = len(os.sched_getaffinity(0))
         threads = max(2, min(16, cpus // max(world, 1)))
-        host_api.set_groups(3)   # three game groups: two forward passes in flight while one group is on the host
+        GROUPS = 4   # game groups: three forward passes queued on the GPU while one group is on the host
+        host_api.set_groups(GROUPS)
         rates, sp_err, secs = [0.0, 0.0], None, 0.0
         try:   # a side measurement must never cost the headline line
-            st = host_api.selfplay_run(path, 3 * args.batch, threads, args.selfplay_seconds, default_n=32,
+            st = host_api.selfplay_run(path, GROUPS * args.batch, threads, args.selfplay_seconds, default_n=32,
                                        default_k=5, selected_n=32, selected_k=5, warmup_batches=4,
                                        seed=sharding.seed_for_rank(77, shard), device=local_rank)
             rates, secs = [st.positions / st.seconds, st.moves / st.seconds], st.seconds
@@ -146,7 +147,7 @@ def main():
             sp_err = repr(ex)
         sp = sharding.sum_over_ranks(shard, rates)
         selfplay = {"value": float(sp[0]), "unit": "positions/s", "moves_per_s": float(sp[1]),
-                    "concurrent_games_per_gpu": 3 * args.batch, "batch": args.batch, "game_groups": 3,
+                    "concurrent_games_per_gpu": GROUPS * args.batch, "batch": args.batch, "game_groups": GROUPS,
                     "host_threads_per_gpu": threads, "seconds": secs,
                     "gumbel": "n=32 (default k<=5, selected k=5)", "includes": "host MCTS + PCIe + engine"}
         if sp_err:

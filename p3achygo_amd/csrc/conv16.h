@@ -21,7 +21,7 @@
 // 2n the even chunk's lanes take the even bank groups and the odd chunk's lanes the odd
 // ones: conflict-free.
 // i.e. again 4 consecutive output channels of ONE board point per accumulator quad, so
-// epilogues keep writing 8-byte fp16 pieces.
+// epilogues keep writing 8-byte fp16 pieces to LDS (16-byte pieces to HBM, see the expand epilogue).
 #pragma once
 #include <type_traits>
 #include "conv_core.h"

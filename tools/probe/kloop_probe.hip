@@ -115,6 +115,62 @@ void run(const char* name, const h8* w, float* out, int steps, int wsteps) {
   printf("%-40s %.3f ms  %.0f TFLOP/s\n", name, ms, flop / ms / 1e9);
 }
 
+// 4 waves per CU (one per SIMD, up to 512 registers each), wave tile 8 x 6: 14 ds_read_b128 per 48 MFMAs.
+__global__ void __launch_bounds__(256, 1) kloop_big(const h8* __restrict__ w, float* out, int steps, int barrier) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  for (int i = threadIdx.x; i < 131072 / 2; i += blockDim.x) ((_Float16*)smem)[i] = (_Float16)(0.01f * ((i * 7 + blockIdx.x) % 61) - 0.3f);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  f32x4 acc[8][6];
+  for (int a = 0; a < 8; ++a) for (int b = 0; b < 6; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+  h8 fa[2][8], fb[6];
+  const uint32_t abase = lane * 16;
+  const uint32_t bbase = 16384 + wid * 24576 + lane * 16;
+  for (int ct = 0; ct < 8; ++ct) { fa[0][ct] = *(h8*)(smem + abase + ct * 1024); fa[1][ct] = fa[0][ct]; }
+  for (int j = 0; j < 6; ++j) fb[j] = *(h8*)(smem + bbase + j * 1024);
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < steps; s += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (j == 0) asm volatile("s_waitcnt lgkmcnt(4)");
+        else if (j >= 2) asm volatile("s_waitcnt lgkmcnt(13)");
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+          acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[u][ct], fb[j], acc[ct][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[j]) : "v"(bbase + ((s + u) & 7) * 16), "i"(0));
+        if (j < 2) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[u ^ 1][4 * j + k]) : "v"(abase + k * 1024), "i"(0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (barrier) __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  float sum = 0;
+  for (int a = 0; a < 8; ++a) for (int b = 0; b < 6; ++b) sum += acc[a][b][0] + acc[a][b][3];
+  out[blockIdx.x * 512 + threadIdx.x] = sum;
+}
+
+void run_big(const h8* w, float* out, int steps, int barrier) {
+  (void)hipFuncSetAttribute((const void*)kloop_big, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int rep = 0; rep < 3; ++rep) kloop_big<<<256, 256, 131072>>>(w, out, steps, barrier);
+  (void)hipEventRecord(e0);
+  for (int rep = 0; rep < 5; ++rep) kloop_big<<<256, 256, 131072>>>(w, out, steps, barrier);
+  (void)hipEventRecord(e1);
+  (void)hipDeviceSynchronize();
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+  const double flop = 16384.0 * 48 * steps * 4 * 256;
+  printf("%-40s %.3f ms  %.0f TFLOP/s\n", barrier ? "4 waves/CU, 8x6 tiles, LDS + barrier" : "4 waves/CU, 8x6 tiles, A+B from LDS", ms, flop / ms / 1e9);
+}
+
 int main() {
   const int steps = 36 * 300, wsteps = 36;
   h8* w; float* out;
@@ -130,6 +186,8 @@ int main() {
     run<3>("B from LDS, A from global (2 ahead)", w, out, steps, wsteps);
     run<4>("A+B from LDS + barrier + LDS-DMA ring", w, out, steps, wsteps);
     run<5>("A+B from LDS + barrier + reg-staged ring", w, out, steps, wsteps);
+    run_big(w, out, steps, 0);
+    run_big(w, out, steps, 1);
   }
   return 0;
 }

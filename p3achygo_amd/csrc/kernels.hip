@@ -519,10 +519,28 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
   // Staging is software-pipelined like the conv kernels': the 12 16-byte loads of the next
   // 128-channel pass (next half or next position) are issued before the current pass's K loop
   // and scattered (transposed) into LDS after the barrier that ends it.
-  using GS = Geo<1, 128, 1>;   // thread -> (channel block, 12 board points) map of stage_load
+  // Thread (combo = channel block of the pass, l32) owns the six PAIRS of adjacent board points
+  // 2*(l32 + 32*i), +1: two adjacent 16-byte loads per pair (still kXLoads = 12 per thread, the
+  // ring's vmcnt bookkeeping is unchanged) and one ds_write_b32 per channel and pair when the
+  // slice is transposed into Tt[c][i] — half the LDS store instructions of a per-point scatter.
+  using GS = Geo<1, 128, 1>;
   constexpr int NHALF = (C + CH - 1) / CH;
   XRegs<GS> xr;
-  stage_load<GS>(xr, a.t, C, blockIdx.x, a.npos, 0);
+  auto pair_load = [&](int pos_, int cblk) {
+    static_assert(kXLoads == 12, "six pairs");
+    int pp = pos_ < a.npos ? pos_ : a.npos - 1;
+    const _Float16* src = a.t + ((size_t)pp * (C / 8) + cblk + (threadIdx.x >> 5)) * (kNLoc * 8);
+    const int l32 = threadIdx.x & 31;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      int l0 = 2 * (l32 + 32 * i), l1 = l0 + 1;
+      if (l0 >= kNLoc) l0 = kNLoc - 1;   // tail lanes re-read a valid item (not stored)
+      if (l1 >= kNLoc) l1 = kNLoc - 1;
+      xr.v[2 * i] = *(const h8*)(src + l0 * 8);
+      xr.v[2 * i + 1] = *(const h8*)(src + l1 * 8);
+    }
+  };
+  pair_load(blockIdx.x, 0);
   for (int pos = blockIdx.x; pos < a.npos; pos += gridDim.x) {
 #pragma unroll 1
     for (int half = 0; half < NHALF; ++half) {
@@ -536,11 +554,14 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
         const int combo = threadIdx.x >> 5, l32 = threadIdx.x & 31;   // combo = channel block of this pass
         if (combo * 8 < nch) {
 #pragma unroll
-          for (int i = 0; i < kXLoads; ++i) {
-            const int loc = l32 + 32 * i;
+          for (int i = 0; i < 6; ++i) {
+            const int loc = 2 * (l32 + 32 * i);
             if (loc >= kNLoc) continue;
+            const h8 v0 = xr.v[2 * i];
+            h8 v1 = xr.v[2 * i + 1];
+            if (loc + 1 >= kNLoc) v1 = h8{0, 0, 0, 0, 0, 0, 0, 0};   // board point 361 is padding (K = 384)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) *(_Float16*)(smem + (combo * 8 + e) * kTtStride + loc * 2) = xr.v[i][e];
+            for (int e = 0; e < 8; ++e) *(h2*)(smem + (combo * 8 + e) * kTtStride + loc * 2) = h2{v0[e], v1[e]};
           }
         }
       }
@@ -549,7 +570,7 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
         if (nhalf == NHALF) { nhalf = 0; npos = pos + gridDim.x; }
         // channel blocks past C (second pass of C = 192) are clamped to a valid block and ignored
         int cblk0 = nhalf * (CH / 8);
-        stage_load<GS>(xr, a.t, C, npos, a.npos, cblk0 + ((threadIdx.x >> 5) * 8 < C - nhalf * CH ? 0 : -(int)(threadIdx.x >> 5)));
+        pair_load(npos, cblk0 + ((threadIdx.x >> 5) * 8 < C - nhalf * CH ? 0 : -(int)(threadIdx.x >> 5)));
         ring_note_xloads(ring);
       }
 #pragma unroll 1
@@ -569,15 +590,25 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
           const int j = jp * 128 + jg * 64 + mt * 32 + lr;
           if (j >= kNLoc) continue;
           const float bj = p_bias[j];
+          // channel blocks g4 = 2*gp and 2*gp + 1: each lane's quad is one 8-byte half of a
+          // block's piece; after the swap lanes 0-31 hold the whole piece of block 2*gp, lanes
+          // 32-63 that of block 2*gp + 1 (see epilogue_store in conv_core.h)
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int c = half * CH + ct * 32 + g4 * 8 + h * 4;
-            const f32x4 sc = *(const f32x4*)(p_scale + c);
-            const f32x4 sh = *(const f32x4*)(p_shift + c);
-            h4 o;
+          for (int gp = 0; gp < 2; ++gp) {
+            h4 o[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (_Float16)mish_f((acc[mt][g4 * 4 + i] + bj) * sc[i] + sh[i]);
-            *(h4*)(a.u + ((size_t)pos * (C / 8) + (c >> 3)) * (kNLoc * 8) + j * 8 + h * 4) = o;
+            for (int k = 0; k < 2; ++k) {
+              const int g4 = 2 * gp + k;
+              const int c = half * CH + ct * 32 + g4 * 8 + h * 4;
+              const f32x4 sc = *(const f32x4*)(p_scale + c);
+              const f32x4 sh = *(const f32x4*)(p_shift + c);
+              const f32x4 v = {acc[mt][g4 * 4] + bj, acc[mt][g4 * 4 + 1] + bj, acc[mt][g4 * 4 + 2] + bj, acc[mt][g4 * 4 + 3] + bj};
+              o[k] = bn_mish4(v, sc, sh);
+            }
+            half_swap32(o[0], o[1]);
+            const h8 piece = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
+            const int cb = (half * CH + ct * 32) / 8 + 2 * gp + h;   // this lane's channel block
+            *(h8*)(a.u + ((size_t)pos * (C / 8) + cb) * (kNLoc * 8) + j * 8) = piece;
           }
         }
       }

@@ -581,7 +581,9 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
         // two k16 steps ahead exactly as in the conv kernels.
         f32x16 acc2[2][1];
         acc_zero<GeoTt, 128>(acc2);
+#if !(P3_EXP & 2048)
         conv_segment<GeoTt, 128, 1, 1, false, true>(ring, smem, acc2);
+#endif
         if (!ct_active) continue;
         const f32x16 acc[2] = {acc2[0][0], acc2[1][0]};
         // epilogue: rows = channel (regs), cols = j (lanes)
@@ -608,7 +610,11 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
             half_swap32(o[0], o[1]);
             const h8 piece = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
             const int cb = (half * CH + ct * 32) / 8 + 2 * gp + h;   // this lane's channel block
+#if (P3_EXP & 4096)
+            asm volatile("" ::"v"(piece));
+#else
             *(h8*)(a.u + ((size_t)pos * (C / 8) + cb) * (kNLoc * 8) + j * 8) = piece;
+#endif
           }
         }
       }

@@ -140,7 +140,7 @@ def main():
         rates, sp_err, secs = [0.0, 0.0], None, 0.0
         try:   # a side measurement must never cost the headline line
             st = host_api.selfplay_run(path, GROUPS * args.batch, threads, args.selfplay_seconds, default_n=32,
-                                       default_k=5, selected_n=32, selected_k=5, warmup_batches=4,
+                                       default_k=5, selected_n=32, selected_k=5, warmup_batches=4 * GROUPS,
                                        seed=sharding.seed_for_rank(77, shard), device=local_rank)
             rates, secs = [st.positions / st.seconds, st.moves / st.seconds], st.seconds
         except Exception as ex:   # noqa: BLE001

@@ -50,10 +50,30 @@ def dump_model_configs():
         json.dump(out, f, indent=1, sort_keys=True)
 
 
-def dump_nn(name, n_pos, seed):
+def wide_positions(n_pos, seed):
+    """Mid / late-game, pass-heavy and both-komi-sign positions, both colours to move."""
+    q = n_pos // 4
+    parts = [
+        features.random_positions(q, seed=seed, max_moves=220, n_games=q),
+        features.random_positions(q, seed=seed + 1, min_moves=120, max_moves=340, n_games=q,
+                                  komis=(7.5, -7.5, 0.5, 6.5, -20.5, 40.5)),
+        features.random_positions(q, seed=seed + 2, min_moves=20, max_moves=300, n_games=q, pass_prob=0.2,
+                                  komis=(7.5, -7.5, 5.5)),
+        features.random_positions(n_pos - 3 * q, seed=seed + 3, min_moves=250, max_moves=420,
+                                  n_games=n_pos - 3 * q, pass_prob=0.05, komis=(7.5, -0.5)),
+    ]
+    return np.concatenate(parts)
+
+
+def dump_nn(name, n_pos, seed, wide=False, peak=0.0, tag="", store=np.float64):
     cfg = netspec.CONFIGS[name]
     W = netspec.generate_weights(cfg, seed=netspec.WEIGHT_SEED, randomize=True)
-    pos = features.random_positions(n_pos, seed=seed, max_moves=220, n_games=n_pos)
+    if peak:
+        W = netspec.peak_policy(W, peak)
+    if wide:
+        pos = wide_positions(n_pos, seed)
+    else:
+        pos = features.random_positions(n_pos, seed=seed, max_moves=220, n_games=n_pos)
     # independent (numpy) statement of LoadPlanes/LoadFeatures for the fixture inputs
     planes = np.zeros((n_pos, 19, 19, 15), np.float32)
     sc = np.zeros((n_pos, 8), np.float32)
@@ -77,12 +97,13 @@ def dump_nn(name, n_pos, seed):
     wsum = float(sum(float(w.astype(np.float64).sum()) for w in W.values()))
     wsq = float(sum(float((w.astype(np.float64) ** 2).sum()) for w in W.values()))
     np.savez_compressed(
-        os.path.join(GOLD, f"nn_{name}.npz"),
+        os.path.join(GOLD, f"nn_{name}{tag}.npz"),
         features=np.frombuffer(pos.tobytes(), np.uint8), n_pos=n_pos, planes=planes.astype(np.uint8),
-        scalars=sc, raw=ref["raw"], move_probs=ref["move_probs"], value_probs=ref["value_probs"],
-        score_probs=ref["score_probs"], opt_move_probs=ref["opt_move_probs"],
-        weight_checksum=np.array([wsum, wsq]))
-    print(name, "ok", ref["raw"].shape)
+        scalars=sc, raw=ref["raw"].astype(store), move_probs=ref["move_probs"].astype(store),
+        value_probs=ref["value_probs"].astype(store),
+        score_probs=ref["score_probs"].astype(store), opt_move_probs=ref["opt_move_probs"].astype(store),
+        weight_checksum=np.array([wsum, wsq]), peak=np.array(float(peak)))
+    print(name + tag, "ok", ref["raw"].shape, "max move prob", float(ref["move_probs"].max()))
 
 
 if __name__ == "__main__":
@@ -96,5 +117,11 @@ if __name__ == "__main__":
     dump_nn("test_b3c384btl3", 3, 18)
     dump_nn("test_b3c384nbt", 3, 19)
     dump_nn("test_b3c192classic", 3, 20)
-    dump_nn("b8c128nbt", 2, 14)
-    dump_nn("b12c256btl3", 2, 15)
+    # full-size BASELINE architectures: wide position sets; outputs stored as float32 (the
+    # float64 results rounded once: 6e-8 relative, three orders below any tolerance)
+    dump_nn("b8c128nbt", 8, 14, wide=True, store=np.float32)                  # C1
+    dump_nn("b12c128btl3", 8, 21, wide=True, store=np.float32)                # C2
+    dump_nn("b12c256btl3", 32, 15, wide=True, store=np.float32)               # C3 / C4 (headline)
+    dump_nn("b12c256btl3", 8, 22, wide=True, peak=12.0, tag="_peaked", store=np.float32)
+    dump_nn("b10c384nbt", 4, 23, wide=True, store=np.float32)                 # C5
+    dump_nn("b14c384btl3", 4, 24, wide=True, store=np.float32)                # C5

@@ -22,6 +22,7 @@
 
 #include "../../include/p3hip.h"
 #include "kernels.h"
+#include "slot_state.h"
 
 namespace {
 
@@ -85,10 +86,23 @@ struct WeightFile {
     }
     return true;
   }
-  const Tensor& get(const std::string& n) const {
+  // A missing or mis-shaped tensor (truncated / foreign file) is recorded and answered with a
+  // zero tensor of the expected size; build_plan checks `missing` once at the end and
+  // p3hip_create fails with the list — the library never aborts the host process.
+  mutable std::string missing;
+  mutable std::vector<std::vector<float>> zeros;
+  mutable std::map<std::string, Tensor> stand_ins;
+  const Tensor& get(const std::string& n, size_t expect = 0) const {
     auto it = tensors.find(n);
-    if (it == tensors.end()) { fprintf(stderr, "p3hip: missing tensor %s\n", n.c_str()); abort(); }
-    return it->second;
+    if (it != tensors.end() && (expect == 0 || it->second.size() == expect)) return it->second;
+    if (missing.size() < 400) missing += (missing.empty() ? "" : ", ") + n + (it == tensors.end() ? "" : " (wrong size)");
+    auto st = stand_ins.find(n);
+    if (st != stand_ins.end()) return st->second;
+    zeros.emplace_back(expect ? expect : 1, 0.0f);
+    Tensor t;
+    t.dims = {(int)zeros.back().size()};
+    t.data = zeros.back().data();
+    return stand_ins[n] = t;
   }
   bool is_broadcast(int i) const { return i % bint == bint - 1; }  // model.py:1002
 };
@@ -176,8 +190,7 @@ struct p3hip_engine {
   float* d_hp = nullptr;
   float* d_out = nullptr;
   float* h_out = nullptr;  // pinned [batch][kResultFloats]
-  std::vector<std::atomic<uint8_t>> loaded;
-  std::vector<int> slot_to_row;  // slot -> dense row of the last run (-1 if absent)
+  p3::SlotStates slots;   // dirty flags + slot -> dense row of the last run (slot_state.h)
   int last_n = 0;
 
   bool check(hipError_t e, const char* what) {
@@ -532,9 +545,7 @@ p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version
   memset(e->h_feats, 0, B * kFeatBytes);
   hipMemset(e->d_feats, 0, B * kFeatBytes);
   hipMemset(e->d_out, 0, B * p3::kOutStride * 4);
-  e->loaded = std::vector<std::atomic<uint8_t>>(B);
-  for (auto& a : e->loaded) a.store(0);
-  e->slot_to_row.assign(B, -1);
+  e->slots = p3::SlotStates((int)B);
   return e;
 }
 
@@ -561,22 +572,16 @@ const char* p3hip_last_error(const p3hip_engine* e) { return e->err.c_str(); }
 int p3hip_load_slot(p3hip_engine* e, int slot, const p3hip_features* f) {
   if (slot < 0 || slot >= e->batch) return 1;
   memcpy(e->h_feats + (size_t)slot * kFeatBytes, f, kFeatBytes);
-  e->loaded[slot].store(1, std::memory_order_release);
+  e->slots.loaded(slot);
   return 0;
 }
 
+// Compacts every dirty slot (loaded and not yet fetched, slot_state.h) into the dense upload.
 static int gather_loaded(p3hip_engine* e) {
-  int n = 0;
   const bool all = (e->flags & P3HIP_FLAG_RUN_ALL_SLOTS) != 0;
-  for (int s = 0; s < e->batch; ++s) {
-    bool on = e->loaded[s].exchange(0, std::memory_order_acquire) != 0;
-    if (on || all) {
-      memcpy(e->h_feats_compact + (size_t)n * kFeatBytes, e->h_feats + (size_t)s * kFeatBytes, kFeatBytes);
-      e->slot_to_row[s] = n++;
-    } else {
-      e->slot_to_row[s] = -1;
-    }
-  }
+  const int n = e->slots.gather(all, [&](int s, int row) {
+    memcpy(e->h_feats_compact + (size_t)row * kFeatBytes, e->h_feats + (size_t)s * kFeatBytes, kFeatBytes);
+  });
   e->last_n = n;
   return n;
 }
@@ -609,7 +614,7 @@ int p3hip_run(p3hip_engine* e) {
 
 int p3hip_get_slot(p3hip_engine* e, int slot, p3hip_result* out) {
   if (slot < 0 || slot >= e->batch) return 1;
-  int row = e->slot_to_row[slot];
+  int row = e->slots.row(slot);
   if (row < 0) return 2;
   const float* r = e->h_out + (size_t)row * p3::kResultFloats;
   memcpy(out->move_logits, r + p3::kOffMoveLogits, 362 * 4);
@@ -618,20 +623,23 @@ int p3hip_get_slot(p3hip_engine* e, int slot, p3hip_result* out) {
   memcpy(out->score_probs, r + p3::kOffScoreProbs, 800 * 4);
   memcpy(out->opt_move_probs, r + p3::kOffOptProbs, 362 * 4);
   out->err2_outcome = r[p3::kOffErr2];
+  e->slots.fetched(slot);
   return 0;
 }
 
 int p3hip_get_ownership(p3hip_engine* e, int slot, float out[P3HIP_NUM_LOCS]) {
   if (slot < 0 || slot >= e->batch) return 1;
-  int row = e->slot_to_row[slot];
+  int row = e->slots.row(slot);
   if (row < 0) return 2;
-  return e->check(hipMemcpy(out, e->d_out + (size_t)row * p3::kOutStride + p3::kOffOwnership,
-                            kNLoc * 4, hipMemcpyDeviceToHost), "D2H ownership") ? 0 : 1;
+  if (!e->check(hipMemcpy(out, e->d_out + (size_t)row * p3::kOutStride + p3::kOffOwnership,
+                          kNLoc * 4, hipMemcpyDeviceToHost), "D2H ownership")) return 1;
+  e->slots.fetched(slot);
+  return 0;
 }
 
 int p3hip_get_raw(p3hip_engine* e, int slot, float* out) {
   if (slot < 0 || slot >= e->batch) return 1;
-  int row = e->slot_to_row[slot];
+  int row = e->slots.row(slot);
   if (row < 0) return 2;
   std::vector<float> rec(p3::kOutStride);
   if (!e->check(hipMemcpy(rec.data(), e->d_out + (size_t)row * p3::kOutStride, p3::kOutStride * 4,

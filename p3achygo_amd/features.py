@@ -151,9 +151,14 @@ def _liberty_planes(board):
     return planes
 
 
-def random_positions(n: int, seed: int = 0, max_moves: int = 250, n_games: int = 0
-                     ) -> np.ndarray:
-    """n seeded random-legal playout positions as a numpy array of `Features` records."""
+def random_positions(n: int, seed: int = 0, max_moves: int = 250, n_games: int = 0,
+                     min_moves: int = 0, pass_prob: float = 0.02, komis=(7.5,)) -> np.ndarray:
+    """n seeded random-legal playout positions as a numpy array of `Features` records.
+
+    The defaults reproduce the round-1 generator bit for bit (fixtures depend on it);
+    min_moves / pass_prob / komis widen the distribution (late-game, pass-heavy, komi of
+    either sign: one komi per game, drawn after the stops so the default stream is unchanged).
+    """
     rng = np.random.default_rng(seed)
     out = np.zeros(n, dtype=features_dtype())
     n_games = n_games or max(1, min(n, 16))
@@ -164,7 +169,8 @@ def random_positions(n: int, seed: int = 0, max_moves: int = 250, n_games: int =
         idxs = per_game[g]
         if not idxs:
             continue
-        stops = sorted(int(rng.integers(0, max_moves + 1)) for _ in idxs)
+        stops = sorted(int(rng.integers(min_moves, max_moves + 1)) for _ in idxs)
+        komi = float(komis[int(rng.integers(0, len(komis)))]) if len(komis) > 1 else float(komis[0])
         board = np.zeros(NUM_LOCS, np.int8)
         hist = []  # (i, j) or pass
         col = 1
@@ -176,7 +182,7 @@ def random_positions(n: int, seed: int = 0, max_moves: int = 250, n_games: int =
                 f = out[k]
                 f["bsize"] = BL
                 f["color"] = col
-                f["komi"] = 7.5
+                f["komi"] = komi
                 f["board"] = board
                 lm = [(-1, -1)] * 5 + hist
                 for t in range(5):
@@ -188,7 +194,7 @@ def random_positions(n: int, seed: int = 0, max_moves: int = 250, n_games: int =
                 si += 1
             # play one random legal move (pass with small probability)
             played = False
-            if rng.random() > 0.02:
+            if rng.random() > pass_prob:
                 for p in rng.permutation(NUM_LOCS)[:40]:
                     if _play(board, int(p), col) >= 0:
                         hist.append(divmod(int(p), BL))

@@ -207,6 +207,24 @@ def generate_weights(cfg: NetConfig, seed: int = WEIGHT_SEED, randomize: bool = 
     return out
 
 
+POLICY_OUT_TENSORS = ("policy.out_moves.w", "policy.out_pass.w", "policy.out_pass.b",
+                      "policy.opt_moves.w", "policy.opt_pass.w", "policy.opt_pass.b")
+
+
+def peak_policy(weights: Dict[str, np.ndarray], scale: float) -> Dict[str, np.ndarray]:
+    """Scales the last linear layer of the policy / optimistic-policy outputs by `scale`.
+
+    Random-init nets have near-uniform policies (logit sigma ~0.35, max prob ~0.01), on which
+    probability tolerances and argmax checks say little.  Scaling the final 1x1 conv / dense
+    multiplies the logits (pass offset excluded) by `scale`, i.e. gives the peaked policies of
+    a trained net while every other tensor keeps its initialiser distribution.
+    """
+    out = dict(weights)
+    for k in POLICY_OUT_TENSORS:
+        out[k] = (weights[k] * np.float32(scale)).astype(np.float32)
+    return out
+
+
 _HDR = struct.Struct("<4s10i")
 _ENT = struct.Struct("<48si4iq")
 

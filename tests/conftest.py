@@ -31,12 +31,15 @@ def weight_files(tmp_path_factory):
     d = tmp_path_factory.mktemp("weights")
     cache = {}
 
-    def get(name, randomize=True):
-        key = (name, randomize)
+    def get(name, randomize=True, peak=0.0):
+        key = (name, randomize, peak)
         if key not in cache:
             cfg = netspec.CONFIGS[name]
-            p = os.path.join(d, f"{name}_{int(randomize)}.p3w")
-            netspec.save_p3w(p, cfg, netspec.generate_weights(cfg, randomize=randomize))
+            p = os.path.join(d, f"{name}_{int(randomize)}_{peak:g}.p3w")
+            W = netspec.generate_weights(cfg, randomize=randomize)
+            if peak:
+                W = netspec.peak_policy(W, peak)
+            netspec.save_p3w(p, cfg, W)
             cache[key] = p
         return cache[key]
     return get

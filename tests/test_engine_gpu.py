@@ -2,8 +2,21 @@
 golden vectors and the CPU oracle on the same seeded inputs.
 
 Tolerance (fp16 trunk with fp32 accumulation vs fp32/float64 reference), stated per
-SURVEY.md §8c and tightened after measurement: logits |d| <= 2e-2 abs, probabilities
-<= 2e-3 abs, argmax of the policy identical on the fixture set.
+SURVEY.md §8c and tightened after measurement (random-init nets: logit sigma ~0.35, largest
+move probability ~0.012; worst case measured on MI355X over all 13 fixtures, round 2,
+tools/gpu_parity_stats.py: logits 4.9e-3 (b8c128nbt), 362/800-way probabilities 3.3e-5,
+outcome probabilities 2.6e-4, KL 6.9e-7):
+  * every raw head output (logits, ownership, q6_err, gamma): |d| <= LOGIT_TOL = 6e-3 abs
+    (1.7 % of the logit sigma);
+  * move / optimistic-move / score probabilities: |d| <= PROB_TOL = 5e-5 abs (0.4 % of the
+    largest move probability); the two-way outcome distribution moves by up to a quarter of
+    its logit-difference error: |d| <= VALUE_PROB_TOL = 5e-4;
+  * KL(reference || engine) <= KL_TOL = 2e-6 for each of the four distributions;
+  * the `_peaked` fixture (policy output layer scaled x12 -> max move probability up to 0.96,
+    the regime of a trained net): policy logits scale with the output layer, so their bound
+    is 12 x LOGIT_TOL (measured 3.0e-2); probabilities |d| <= 1e-2 (measured 3.3e-3),
+    KL <= 2e-4 (measured 2.4e-5), argmax and top-3 identical.
+The reference itself pins no network numerics ("parity unpinned").
 """
 import os
 import threading
@@ -15,39 +28,101 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = 2e-2
-PROB_TOL = 2e-3
-NETS = ["test_b3c128btl2", "test_b3c128nbt", "test_b3c256btl1", "test_b3c256nbt", "test_b3c384btl3", "test_b3c384nbt", "test_b3c192classic", "b8c128nbt",
-        "b12c256btl3"]
+LOGIT_TOL = 6e-3
+PROB_TOL = 5e-5
+VALUE_PROB_TOL = 5e-4
+KL_TOL = 2e-6
+PEAK_PROB_TOL = 1e-2
+PEAK_KL_TOL = 2e-4
+# the last six are full-size BASELINE architectures: C1 b8c128nbt, C2 b12c128btl3, C3/C4
+# b12c256btl3 (32 wide positions + a peaked-policy set), C5 b10c384nbt / b14c384btl3
+NETS = ["test_b3c128btl2", "test_b3c128nbt", "test_b3c256btl1", "test_b3c256nbt", "test_b3c384btl3", "test_b3c384nbt",
+        "test_b3c192classic", "b8c128nbt", "b12c128btl3", "b12c256btl3", "b12c256btl3_peaked", "b10c384nbt",
+        "b14c384btl3"]
+PROB_KEYS = ("move_probs", "value_probs", "score_probs", "opt_move_probs")
 
 
-def _check(raw, res, ref_raw, ref):
+def _kl(p, q):
+    p = np.asarray(p, np.float64)
+    q = np.maximum(np.asarray(q, np.float64), 1e-300)
+    m = p > 0
+    return float((p[m] * np.log(p[m] / q[m])).sum())
+
+
+def _check(raw, res, ref_raw, ref, peak=0.0):
     assert not np.isnan(raw).any()
-    assert np.abs(raw[:1887] - ref_raw[:1887]).max() <= LOGIT_TOL
+    pol = peak if peak else 1.0            # the policy logits scale with the peaked output layer
+    assert np.abs(raw[:724] - ref_raw[:724]).max() <= LOGIT_TOL * pol
+    assert np.abs(raw[724:1887] - ref_raw[724:1887]).max() <= LOGIT_TOL
     assert abs(raw[1887] - ref_raw[1887]) <= LOGIT_TOL and abs(raw[1888] - ref_raw[1888]) <= LOGIT_TOL
-    for key in ("move_probs", "value_probs", "score_probs", "opt_move_probs"):
+    for key in PROB_KEYS:
         got = np.ctypeslib.as_array(getattr(res, key))
-        assert np.abs(got - ref[key]).max() <= PROB_TOL, key
+        policy = key in ("move_probs", "opt_move_probs")
+        ptol, ktol = (PEAK_PROB_TOL, PEAK_KL_TOL) if (peak and policy) else (PROB_TOL, KL_TOL)
+        if key == "value_probs":
+            ptol = VALUE_PROB_TOL
+        assert np.abs(got - ref[key]).max() <= ptol, key
+        assert _kl(ref[key], got) <= ktol, key
         assert abs(got.sum() - 1.0) < 1e-4, key
-    assert np.ctypeslib.as_array(res.move_probs).argmax() == ref["move_probs"].argmax()
+    if peak:
+        mp = np.ctypeslib.as_array(res.move_probs)
+        assert mp.argmax() == ref["move_probs"].argmax()
+        assert set(np.argsort(mp)[-3:]) == set(np.argsort(ref["move_probs"])[-3:])
     assert np.array_equal(np.ctypeslib.as_array(res.move_logits), raw[:362])
+
+
+def _weights_for(weight_files, name):
+    """.p3w of a golden fixture: `<config>_peaked` = the config with the policy output layer x12."""
+    if name.endswith("_peaked"):
+        return weight_files(name[:-len("_peaked")], peak=12.0)
+    return weight_files(name)
 
 
 @pytest.mark.parametrize("name", NETS)
 def test_engine_matches_golden(built, weight_files, name):
     from p3achygo_amd import engine
     g, pos = load_golden(name)
-    eng = engine.create_engine(engine.kind_from_engine_path(weight_files(name)),
-                               weight_files(name), 8, 1)
-    assert eng.kind() == engine.Kind.kHip and eng.path() == weight_files(name)
+    wpath = _weights_for(weight_files, name)
+    peak = float(g["peak"])
+    assert (peak > 0) == name.endswith("_peaked")
+    eng = engine.create_engine(engine.kind_from_engine_path(wpath), wpath, max(8, len(pos)), 1)
+    assert eng.kind() == engine.Kind.kHip and eng.path() == wpath
     for i in range(len(pos)):
         eng.LoadBatch(i, pos[i:i + 1])
     eng.RunInference()
     for i in range(len(pos)):
-        ref = {k: g[k][i] for k in ("move_probs", "value_probs", "score_probs", "opt_move_probs")}
-        _check(eng.get_raw(i), eng.GetBatch(i), g["raw"][i], ref)
+        ref = {k: g[k][i] for k in PROB_KEYS}
+        _check(eng.get_raw(i), eng.GetBatch(i), g["raw"][i], ref, peak)
         own = eng.GetOwnership(i)
         assert np.abs(own - g["raw"][i][1526:1887]).max() <= LOGIT_TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("name,batch", [("b12c128btl3", 256), ("b10c384nbt", 96), ("b14c384btl3", 96)])
+def test_baseline_configs_full_size(built, weight_files, name, batch):
+    """BASELINE configs C2 (b12c128btl3, 256 games, batch 256) and C5 (b10c384nbt / b14c384btl3)
+    at full depth: the golden positions placed at scattered slots of a full batch of other
+    positions must reproduce the float64 fixture, and a strided sample of the rest must agree
+    with the CPU oracle."""
+    from oracle import oracle
+    from p3achygo_amd import engine, features
+    g, gpos = load_golden(name)
+    wpath = weight_files(name)
+    fill = features.random_positions(batch, seed=41, n_games=16, max_moves=300, komis=(7.5, -7.5, 0.5))
+    slots = [int(s) for s in np.linspace(0, batch - 1, len(gpos)).round()]
+    pos = fill.copy()
+    pos[slots] = gpos
+    eng = engine.create_engine(engine.kind_from_engine_path(wpath), wpath, batch, 1)
+    eng.load_all(pos)
+    eng.RunInference()
+    for k, s in enumerate(slots):
+        ref = {key: g[key][k] for key in PROB_KEYS}
+        _check(eng.get_raw(s), eng.GetBatch(s), g["raw"][k], ref)
+    sample = [s for s in range(3, batch, batch // 6) if s not in slots][:6]
+    res, raw = oracle.OracleNet(wpath).forward_features(pos[sample], nthreads=8)
+    for k, s in enumerate(sample):
+        ref = {key: np.ctypeslib.as_array(getattr(res[k], key)) for key in PROB_KEYS}
+        _check(eng.get_raw(s), eng.GetBatch(s), raw[k], ref)
     eng.close()
 
 

@@ -120,13 +120,32 @@ def test_oracle_matches_golden(built, weight_files, name):
         assert np.array_equal(np.ctypeslib.as_array(res[i].move_logits), raw[i][:362])
 
 
-def test_oracle_matches_golden_b12c256btl3(built, weight_files):
-    """Headline architecture, 2 positions (about 1 s of CPU)."""
+@pytest.mark.parametrize("name", ["b8c128nbt", "b12c128btl3", "b12c256btl3", "b12c256btl3_peaked", "b10c384nbt",
+                                  "b14c384btl3"])
+def test_oracle_matches_golden_full_size(built, weight_files, name):
+    """The BASELINE architectures at full depth (C1, C2, C3 incl. the peaked-policy set, C5):
+    fp32 C oracle vs the float64 restatement's committed outputs (stored as float32)."""
     from oracle import oracle
-    g, pos = load_golden("b12c256btl3")
-    net = oracle.OracleNet(weight_files("b12c256btl3"))
-    _, raw = net.forward_features(pos, nthreads=2)
-    assert np.abs(raw - g["raw"]).max() < 1e-4
+    from p3achygo_amd import netspec
+    g, pos = load_golden(name)
+    peak = float(g["peak"])
+    base = name[:-len("_peaked")] if peak else name
+    W = netspec.generate_weights(netspec.CONFIGS[base], randomize=True)
+    if peak:
+        W = netspec.peak_policy(W, peak)
+    wsum = sum(float(w.astype(np.float64).sum()) for w in W.values())
+    wsq = sum(float((w.astype(np.float64) ** 2).sum()) for w in W.values())
+    assert np.allclose([wsum, wsq], g["weight_checksum"], rtol=1e-9)
+    net = oracle.OracleNet(weight_files(base, peak=peak))
+    res, raw = net.forward_features(pos, nthreads=8)
+    tol = np.full(1889, 1e-4)
+    if peak:
+        tol[:724] *= peak
+    assert (np.abs(raw - g["raw"]) <= tol).all()
+    for i in range(len(pos)):
+        for key in ("move_probs", "value_probs", "score_probs", "opt_move_probs"):
+            got = np.ctypeslib.as_array(getattr(res[i], key))
+            assert np.abs(got - g[key][i]).max() < (2e-4 if peak else 2e-6), (key, i)
 
 
 def test_oracle_agrees_with_torch_restatement_fresh_init(built, weight_files):

@@ -19,6 +19,15 @@
  * called by one thread at a time and never overlaps get_slot.  A load_slot on a slot that
  * is not part of the running batch may overlap p3hip_run.
  *
+ * Which slots a run evaluates: every slot that has been loaded and whose result has not been
+ * fetched yet (p3hip_get_slot / p3hip_get_ownership), compacted into a dense batch.  A slot
+ * stays in that set until its result is fetched, not merely until a run has picked it up: the
+ * reference's infer thread may start a run while a worker's LoadBatch is landing
+ * (cc/nn/nn_interface.cc:351-361) and only count that worker as loaded for the NEXT run, which
+ * must then still produce its result.  A slot that has not been evaluated by the last run
+ * answers p3hip_get_slot with 2.  Every entry point binds the engine's HIP device on the
+ * calling thread, so an engine may be driven from any host thread.
+ *
  * Error convention: the reference aborts on failure (trt_engine.cc:27-35).  The C ABI
  * returns status codes and keeps a per-engine message (p3hip_last_error); the C++ adapter
  * CHECK-fails on non-zero, reproducing the reference behaviour.
@@ -84,9 +93,6 @@ typedef struct p3hip_engine p3hip_engine;
 
 /* p3hip_create flags */
 #define P3HIP_FLAG_NONE 0u
-#define P3HIP_FLAG_NO_GRAPH 1u      /* reserved: kernels are always launched eagerly (11 launches of
-                                       0.07-1.5 ms per forward pass of b12c256btl3; launch cost is
-                                       hidden behind the running kernels) */
 #define P3HIP_FLAG_RUN_ALL_SLOTS 2u /* always run the full static batch (TRT behaviour,
                                        trt_engine.cc:238-304); default compacts to loaded slots */
 
@@ -105,10 +111,11 @@ int p3hip_batch_size(const p3hip_engine* e);
 
 /* LoadBatch: copy the features of one position into pinned staging slot `slot`. */
 int p3hip_load_slot(p3hip_engine* e, int slot, const p3hip_features* f);
-/* RunInference: H2D of loaded slots, one forward pass, D2H of results, stream sync.
- * Returns 0 on success. */
+/* RunInference: H2D of the loaded-and-unfetched slots, one forward pass, D2H of results,
+ * stream sync.  Returns 0 on success (also when no slot is pending: nothing is launched). */
 int p3hip_run(p3hip_engine* e);
-/* GetBatch: copy the results of slot `slot` of the last p3hip_run. */
+/* GetBatch: copy the results of slot `slot` of the last p3hip_run and mark the slot fetched.
+ * Returns 2 if the last run did not evaluate the slot (`out` is left untouched). */
 int p3hip_get_slot(p3hip_engine* e, int slot, p3hip_result* out);
 /* GetOwnership: tanh ownership map of slot `slot` (the TRT engine leaves this
  * unsupported, trt_engine.cc:353-356; the HIP engine provides it). */
@@ -136,10 +143,6 @@ int p3hip_get_raw(p3hip_engine* e, int slot, float* out);
  * unpadded 361 points). */
 double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
                                double* flops_per_launch, const char** kernel_name);
-/* Diagnostic build of the fused block kernel with in-kernel s_memtime stamps at phase
- * boundaries (C=256 btl3 nets only).  Returns the grid size (>0) or <=0 on error. */
-int p3hip_debug_block_stamps(p3hip_engine* e, int n_positions, unsigned long long* out,
-                             int max_u64);
 /* Algorithmic FLOPs (2*MAC) of one position: total, and 3x3 trunk convs only. */
 void p3hip_flops_per_position(const p3hip_engine* e, double* total, double* conv3x3);
 

@@ -26,10 +26,6 @@
 #include <type_traits>
 #include "conv_core.h"
 
-#ifndef P3_EXP
-#define P3_EXP 0   // timing experiments (results are garbage): 1 no lgkm waits, 2 no fetch, 8 no ring acquire
-#endif
-
 namespace p3 {
 
 template <class G, int COUT_PASS>
@@ -82,14 +78,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Addressing: one VGPR per 32-row tile pair (at kernel row ky, leftmost tap);
 // kernel column kx, the odd 16-row tile and the k32 index inside the tap are immediates.
 // Body = one kernel row (KW taps), runtime loop over ky.
-template <class G, int COUT_PASS, int KW, int NTAPS_PAD, bool STAMPS = false, int NTn = 0>
+template <class G, int COUT_PASS, int KW, int NTAPS_PAD, int NTn = 0>
 __device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS)>& ring, char* smem,
                                                f32x4 (&acc)[4][NTn]) {
   using T = Tiling16<G, COUT_PASS>;
   static_assert(NTn == T::NT, "accumulator shape");
   static_assert(G::CB % 32 == 0 && NTAPS_PAD == KW * KW, "k32 steps, unpadded taps");
-  if constexpr ((P3_EXP & 128) != 0 && KW == 1) return;   // timing experiment: no 1x1 segments
-  if constexpr ((P3_EXP & 256) != 0 && KW == 3) return;   // timing experiment: no 3x3 segments
   constexpr int NT = T::NT, NB = NT / 2;
   constexpr int NQ = G::CB / 32;                   // k32-steps per tap
   constexpr int U = KW * NQ;                       // unrolled body: one kernel row
@@ -119,9 +113,8 @@ __device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS)>&
       // mid-segment acquires leave this wave's B_2'..B_(NT-1)' reloads of the previous
       // step in flight: every A read of the macro-step being recycled is older than them
       if constexpr (kk == 0) {
-        if constexpr ((P3_EXP & 8) != 0) a_addr = ring.lds_base + a_off;
-        else if constexpr (v == 0) a_addr = ring_acquire<STAMPS, 0>(ring, smem) + a_off;
-        else a_addr = ring_acquire<STAMPS, NT - 2>(ring, smem) + a_off;
+        if constexpr (v == 0) a_addr = ring_acquire<0>(ring, smem) + a_off;
+        else a_addr = ring_acquire<NT - 2>(ring, smem) + a_off;
       }
       if constexpr (vv == 0) {
         const int ky = o + v / U;
@@ -146,9 +139,7 @@ __device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS)>&
     const bool last_body = (NOUT == 1) || (o + 1 == NOUT);
     static_for<0, U>([&](auto UU) {
       constexpr int u = decltype(UU)::value;
-      bool do_fetch = (u + 1 < U) || !last_body;
-      if (STAMPS && (ring.dbg & 2)) do_fetch = false;  // timing experiment: MFMAs only
-      if (P3_EXP & 2) do_fetch = false;
+      const bool do_fetch = (u + 1 < U) || !last_body;
       static_for<0, NT>([&](auto J) {
         constexpr int j = decltype(J)::value;
         // group 0 needs B_0 and the four A fragments (A_3' is the youngest): only
@@ -156,8 +147,7 @@ __device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS)>&
         // Group j >= 2 needs B_j': younger are B_(j+1)'.. plus this step's reads so far
         // (groups 0, 1: three each, groups 2..j-1: one each) = NT + 3, or NT - 1 - j
         // when this step fetches nothing.
-        if constexpr ((P3_EXP & 1) != 0) {
-        } else if constexpr (j == 0) wait_lgkm<NT - 2>();
+        if constexpr (j == 0) wait_lgkm<NT - 2>();
         else if constexpr (j >= 2) {
           if (do_fetch) wait_lgkm<NT + 3>();
           else wait_lgkm<NT - 1 - j>();
@@ -290,8 +280,7 @@ __device__ __forceinline__ void residual_load16(ResRegs16<NTn>& rr, const _Float
     const char* xc = (const char*)x + (size_t)ct * (2 * kNLoc * 8 * 2);   // channel block +2 per cout tile
 #pragma unroll
     for (int b = 0; b < NTn / 2; ++b) {
-      if constexpr ((P3_EXP & 16) != 0) rr.rv[b][ct] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-      else rr.rv[b][ct] = *(const h8*)(xc + (uint32_t)(rr.base[b] * 2u));
+      rr.rv[b][ct] = *(const h8*)(xc + (uint32_t)(rr.base[b] * 2u));
     }
   }
 }
@@ -354,8 +343,7 @@ __device__ __forceinline__ void epilogue_store16(f32x4 (&acc)[4][NTn], const Res
       }
       half_swap(o0, o1);   // every lane takes part: partners of invalid rows may be valid
       const h8 piece = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
-      if constexpr ((P3_EXP & 32) != 0) asm volatile("" ::"v"(piece));
-      else if (rr.ok[b]) *(h8*)(xc + (uint32_t)(rr.base[b] * 2u)) = piece;
+      if (rr.ok[b]) *(h8*)(xc + (uint32_t)(rr.base[b] * 2u)) = piece;
     }
   }
 }

@@ -131,8 +131,6 @@ struct Ring {
   uint32_t lds_base;   // byte offset of the ring inside the dynamic LDS array
   int tol;             // acquires left that must tolerate `extra` younger register loads/stores
   int extra;           // 12, 24, 36 or 48 (see ring_note_inflight)
-  unsigned long long wait_cycles;  // diagnostic builds: cycles spent in ring_acquire waits
-  int dbg;             // diagnostic builds: bit0 = skip waits/barriers/prefetch (timing only)
 };
 
 // Register prefetch of the next activation slice: every thread issues exactly kXLoads
@@ -176,8 +174,6 @@ __device__ __forceinline__ void ring_init(Ring<RS>& r, char* smem, const void* g
   }
   r.tol = 0;
   r.extra = 0;
-  r.wait_cycles = 0;
-  r.dbg = 0;
   for (int i = 0; i < kRingDepth; ++i) ring_issue(r, smem);
 }
 
@@ -206,18 +202,9 @@ __device__ __forceinline__ void ring_retarget(Ring<RS>& r, const void* gbase) {
 // the first acquire of a segment (it doubles as the "previous layer written" barrier); a
 // K loop that knows how many reads it issued after the last fragment read of the macro-step
 // being recycled passes that count instead and does not stall on its own recent reads.
-template <bool STAMPS = false, int LGKM = 0, int RS = 0>
+template <int LGKM = 0, int RS = 0>
 __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
   static_assert(kRingDepth == 2 && kXLoads == 12, "vmcnt immediates below");
-  unsigned long long t0 = 0;
-  if (STAMPS) {
-    if (r.dbg & 1) {  // timing experiment: no synchronisation at all (results are garbage)
-      const uint32_t off = r.use[0];
-      rotate_left(r.use);
-      return off;
-    }
-    t0 = __builtin_amdgcn_s_memtime();
-  }
   constexpr int G = Ring<RS>::G;  // base immediate (D-1)*G = G
   if (r.tol > 0) {
     r.tol--;
@@ -238,11 +225,8 @@ __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
     if (G == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
     else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
   }
-#if !defined(P3_EXP) || !(P3_EXP & 4)
   __builtin_amdgcn_s_barrier();
-#endif
   asm volatile("" ::: "memory");
-  if (STAMPS) r.wait_cycles += __builtin_amdgcn_s_memtime() - t0;
   ring_issue(r, smem);
   const uint32_t off = r.use[0];
   rotate_left(r.use);
@@ -334,7 +318,7 @@ __device__ __forceinline__ void wait_lgkm_n(int n) {
 // loop; a new ring slot is acquired whenever the step being FETCHED enters a macro-step.
 // SWAP: issue mfma(act fragment, weight fragment) instead, i.e. D[act row][weight row]: a lane
 // then holds 4 consecutive ACT rows for one weight row (k_bdense: rows are channels).
-template <class G, int COUT_PASS, int KW, int NTAPS_PAD, bool STAMPS = false, bool SWAP = false, int NTn = 0>
+template <class G, int COUT_PASS, int KW, int NTAPS_PAD, bool SWAP = false, int NTn = 0>
 __device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS)>& ring, char* smem,
                                              f32x16 (&acc)[2][NTn]) {
   using T = Tiling<G, COUT_PASS>;
@@ -376,7 +360,7 @@ __device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS)>& r
     constexpr int KB = COUT_PASS * 32;         // bytes per k16 block
     const int kk = vv % T::KMS;
     if (pc == 0) {
-      if (kk == 0) a_addr = ring_acquire<STAMPS>(ring, smem) + a_off;
+      if (kk == 0) a_addr = ring_acquire(ring, smem) + a_off;
       if (vv % NQ == 0) {
         const int tap = ob * (U / NQ) + vv / NQ;
         int shift = 0;
@@ -444,8 +428,7 @@ __device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS)>& r
       // step u's fragments are complete once at most the following step's reads remain
       if (u + 1 < U || !last_body) wait_lgkm<NLD>();
       else wait_lgkm<0>();
-      bool do_fetch = (u + 2 < U) || !last_body;
-      if (STAMPS && (ring.dbg & 2)) do_fetch = false;  // timing experiment: MFMAs only
+      const bool do_fetch = (u + 2 < U) || !last_body;
 #pragma unroll
       for (int m = 0; m < 2 * T::NT; ++m) {
         const int mt = m / T::NT, j = m % T::NT;

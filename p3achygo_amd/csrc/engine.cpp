@@ -60,6 +60,9 @@ struct WeightFile {
     version = hdr[0]; nblocks = hdr[1]; C = hdr[2]; Cb = hdr[3]; H = hdr[4]; V = hdr[5];
     bint = hdr[6]; inner = hdr[7]; btype = hdr[8];
     int nt = hdr[9];
+    if (nt < 1 || nt > 8192 || nblocks < 1 || nblocks > 256 || bint < 1) {
+      err = "implausible .p3w header"; fclose(f); return false;
+    }
     struct Ent { char name[48]; int ndim; int dims[4]; long long off; };
     std::vector<Ent> ents(nt);
     long long total = 0;
@@ -69,7 +72,13 @@ struct WeightFile {
         err = "truncated tensor table"; fclose(f); return false;
       }
       long long sz = 1;
-      for (int d = 0; d < e.ndim; ++d) sz *= e.dims[d];
+      bool ok = e.ndim >= 0 && e.ndim <= 4 && e.off >= 0 && e.off < (1ll << 31);
+      for (int d = 0; ok && d < e.ndim; ++d) {
+        ok = e.dims[d] > 0 && e.dims[d] < (1 << 24);
+        sz *= e.dims[d];
+        ok = ok && sz < (1ll << 31);
+      }
+      if (!ok) { err = "corrupt tensor table"; fclose(f); return false; }
       if (e.off + sz > total) total = e.off + sz;
     }
     long pos = ftell(f);
@@ -82,7 +91,7 @@ struct WeightFile {
       Tensor t;
       t.dims.assign(e.dims, e.dims + e.ndim);
       t.data = data.data() + e.off;
-      tensors[std::string(e.name)] = t;
+      tensors[std::string(e.name, strnlen(e.name, sizeof e.name))] = t;
     }
     return true;
   }
@@ -110,6 +119,7 @@ struct WeightFile {
 // ---- device arena -----------------------------------------------------------------
 struct Arena {
   std::vector<unsigned char> host;
+  bool bad_stream = false;
   size_t add(const void* p, size_t bytes) {
     size_t off = (host.size() + 255) & ~size_t(255);
     host.resize(off + bytes);
@@ -200,16 +210,19 @@ struct p3hip_engine {
   }
   template <class T>
   const T* dev(size_t off) const { return reinterpret_cast<const T*>(d_arena + off); }
+  // HIP's current device is per host thread, and the ABI is called from whatever thread the
+  // host likes (the infer thread, one GPU thread per game group, a rank's main thread): every
+  // entry point that touches HIP binds the engine's device first.
+  bool bind() { return check(hipSetDevice(device), "hipSetDevice"); }
 };
 
 namespace {
 
-FoldedBN fold_bn(Arena& ar, const WeightFile& wf, const std::string& prefix) {
-  const Tensor& g = wf.get(prefix + ".gamma");
-  const Tensor& b = wf.get(prefix + ".beta");
-  const Tensor& m = wf.get(prefix + ".mean");
-  const Tensor& v = wf.get(prefix + ".var");
-  size_t n = g.size();
+FoldedBN fold_bn(Arena& ar, const WeightFile& wf, const std::string& prefix, size_t n) {
+  const Tensor& g = wf.get(prefix + ".gamma", n);
+  const Tensor& b = wf.get(prefix + ".beta", n);
+  const Tensor& m = wf.get(prefix + ".mean", n);
+  const Tensor& v = wf.get(prefix + ".var", n);
   std::vector<float> sc(n), sh(n);
   for (size_t i = 0; i < n; ++i) {
     sc[i] = g.data[i] / std::sqrt(v.data[i] + kBnEps);
@@ -223,9 +236,11 @@ FoldedBN fold_bn(Arena& ar, const WeightFile& wf, const std::string& prefix) {
 
 // A stream is a whole number of macro-steps of 4 k16 blocks = cout_pass * 128 bytes
 // (conv_core.h ring_slot_bytes).
+// A stream that is not a whole number of macro-steps is a packing bug: it is reported through
+// Arena::bad_stream and fails p3hip_create (never abort() inside the library).
 size_t add_stream(Arena& ar, const std::vector<_Float16>& s, int& nms, int cout_pass) {
   const size_t ms = (size_t)cout_pass * 128;
-  if (s.size() * 2 % ms != 0) { fprintf(stderr, "p3hip: stream not macro-step aligned\n"); abort(); }
+  if (s.size() * 2 % ms != 0) ar.bad_stream = true;
   nms = (int)(s.size() * 2 / ms);
   return ar.add(s.data(), s.size() * 2);
 }
@@ -249,31 +264,34 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
   // init conv
   {
     std::vector<_Float16> s;
-    const Tensor& w = wf.get("init_conv.w");  // [5][5][15][C]
+    const Tensor& w = wf.get("init_conv.w", (size_t)25 * 15 * C);  // [5][5][15][C]
     for (int cp = 0; cp < C / CPI; ++cp)
       pack_segment(s, w.data, 25, 28, 15, C, 0, 16, cp * CPI, CPI);
     e->init_stream_off = add_stream(ar, s, e->init_nms, CPI);
-    e->game_w_off = ar.add(wf.get("init_game.w").data, 8 * C * 4);
-    e->game_b_off = ar.add(wf.get("init_game.b").data, C * 4);
+    e->game_w_off = ar.add(wf.get("init_game.w", (size_t)8 * C).data, 8 * C * 4);
+    e->game_b_off = ar.add(wf.get("init_game.b", (size_t)C).data, C * 4);
   }
   bool have_xa = false;   // layer-wise path: u holds mish(bn0(x)) of the next block
   for (int i = 0; i < wf.nblocks; ++i) {
     BlockPlan bp;
     const std::string p = "blocks." + std::to_string(i);
-    auto W = [&](int j) { return wf.get(p + ".conv" + std::to_string(j) + ".w").data; };
+    // conv j of this block, checked against the [k][k][cin][cout] size the packer will read
+    auto W = [&](int j, int kw, int cin, int cout) {
+      return wf.get(p + ".conv" + std::to_string(j) + ".w", (size_t)kw * kw * cin * cout).data;
+    };
     if (wf.is_broadcast(i)) {
       bp.kind = 3;
       have_xa = false;
-      bp.bn[0] = fold_bn(ar, wf, p + ".bn0");
-      bp.bn[1] = fold_bn(ar, wf, p + ".bn1");
+      bp.bn[0] = fold_bn(ar, wf, p + ".bn0", C);
+      bp.bn[1] = fold_bn(ar, wf, p + ".bn1", C);
       const int CPb = (CB == 128) ? 128 : 64;
       std::vector<_Float16> s0, s1, s2;
       for (int cp = 0; cp < C / CPb; ++cp)
         for (int ip = 0; ip < C / CB; ++ip) {
-          pack_segment(s0, W(0), 1, 1, C, C, ip * CB, CB, cp * CPb, CPb);
-          pack_segment(s2, W(1), 1, 1, C, C, ip * CB, CB, cp * CPb, CPb);
+          pack_segment(s0, W(0, 1, C, C), 1, 1, C, C, ip * CB, CB, cp * CPb, CPb);
+          pack_segment(s2, W(1, 1, C, C), 1, 1, C, C, ip * CB, CB, cp * CPb, CPb);
         }
-      const Tensor& dw = wf.get(p + ".dense.w");  // [361 i][361 j]
+      const Tensor& dw = wf.get(p + ".dense.w", (size_t)kNLoc * kNLoc);  // [361 i][361 j]
       for (int jp = 0; jp < 3; ++jp)
         for (int q = 0; q < 24; ++q)
           for (int h = 0; h < 2; ++h)
@@ -286,11 +304,11 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
       bp.stream_off = add_stream(ar, s0, bp.nms, CPb);
       bp.stream2_off = add_stream(ar, s1, bp.nms2, 128);
       bp.stream3_off = add_stream(ar, s2, bp.nms3, CPb);
-      bp.dense_bias_off = ar.add(wf.get(p + ".dense.b").data, kNLoc * 4);
+      bp.dense_bias_off = ar.add(wf.get(p + ".dense.b", (size_t)kNLoc).data, kNLoc * 4);
     } else if (layerwise) {
       bp.kind = 4;
       const int nconv = classic ? 2 : ((wf.btype == 0) ? wf.inner + 2 : 6);
-      for (int j = 0; j < nconv; ++j) bp.bn[j] = fold_bn(ar, wf, p + ".bn" + std::to_string(j));
+      for (int j = 0; j < nconv; ++j) bp.bn[j] = fold_bn(ar, wf, p + ".bn" + std::to_string(j), (classic || j == 0) ? C : Cb);
       // The consumer's prologue (BN + mish of its input) is applied ONCE by the producer: a
       // layer either stores its output already activated for the next conv (act), or stores it
       // raw and a second, activated copy (dual).  Only the first layer after the init conv or
@@ -298,14 +316,14 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
       // an output pass would otherwise redo that VALU work.  `xa` = activated copy of x, in u.
       FoldedBN next_bn0{};
       const bool next_layerwise = i + 1 < wf.nblocks && !wf.is_broadcast(i + 1);
-      if (next_layerwise) next_bn0 = fold_bn(ar, wf, "blocks." + std::to_string(i + 1) + ".bn0");
+      if (next_layerwise) next_bn0 = fold_bn(ar, wf, "blocks." + std::to_string(i + 1) + ".bn0", C);
       const FoldedBN none{};
       auto add_layer = [&](int j, int kw, int cin, int cout, bool pre, const FoldedBN& pre_bn, bool act, bool res,
                            bool dual, const FoldedBN& out_bn, int in_buf, int out_buf, int out2_buf) {
         LayerPlan lp{kw, cin, cout, pre, act, res, dual, pre_bn, out_bn, in_buf, out_buf, out2_buf};
         std::vector<_Float16> s;
         for (int cp = 0; cp < cout / 64; ++cp)
-          for (int ip = 0; ip < cin / 64; ++ip) pack_segment(s, W(j), kw * kw, kw * kw, cin, cout, ip * 64, 64, cp * 64, 64);
+          for (int ip = 0; ip < cin / 64; ++ip) pack_segment(s, W(j, kw, cin, cout), kw * kw, kw * kw, cin, cout, ip * 64, 64, cp * 64, 64);
         lp.stream_off = add_stream(ar, s, lp.nms, 64);
         bp.layers.push_back(lp);
       };
@@ -334,11 +352,11 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
     } else {
       bp.kind = wf.btype;
       const int nconv = (wf.btype == 0) ? wf.inner + 2 : 6;
-      for (int j = 0; j < nconv; ++j) bp.bn[j] = fold_bn(ar, wf, p + ".bn" + std::to_string(j));
+      for (int j = 0; j < nconv; ++j) bp.bn[j] = fold_bn(ar, wf, p + ".bn" + std::to_string(j), j == 0 ? C : Cb);
       std::vector<_Float16> s;
-      for (int ip = 0; ip < C / CB; ++ip) pack_segment(s, W(0), 1, 1, C, Cb, ip * CB, CB, 0, CB);
-      for (int j = 1; j < nconv - 1; ++j) pack_segment(s, W(j), 9, 9, Cb, Cb, 0, CB, 0, CB);
-      for (int cp = 0; cp < C / CB; ++cp) pack_segment(s, W(nconv - 1), 1, 1, Cb, C, 0, CB, cp * CB, CB);
+      for (int ip = 0; ip < C / CB; ++ip) pack_segment(s, W(0, 1, C, Cb), 1, 1, C, Cb, ip * CB, CB, 0, CB);
+      for (int j = 1; j < nconv - 1; ++j) pack_segment(s, W(j, 3, Cb, Cb), 9, 9, Cb, Cb, 0, CB, 0, CB);
+      for (int cp = 0; cp < C / CB; ++cp) pack_segment(s, W(nconv - 1, 1, Cb, C), 1, 1, Cb, C, 0, CB, cp * CB, CB);
       bp.stream_off = add_stream(ar, s, bp.nms, CB);
     }
     e->blocks.push_back(bp);
@@ -346,9 +364,9 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
   // heads: conv_p | conv_g | value.conv  -> [C][96]
   {
     std::vector<float> w((size_t)C * 96);
-    const float* wp = wf.get("policy.conv_p.w").data;
-    const float* wg = wf.get("policy.conv_g.w").data;
-    const float* wv = wf.get("value.conv.w").data;
+    const float* wp = wf.get("policy.conv_p.w", (size_t)C * 32).data;
+    const float* wg = wf.get("policy.conv_g.w", (size_t)C * 32).data;
+    const float* wv = wf.get("value.conv.w", (size_t)C * 32).data;
     for (int c = 0; c < C; ++c)
       for (int o = 0; o < 32; ++o) {
         w[(size_t)c * 96 + o] = wp[c * 32 + o];
@@ -359,20 +377,30 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
     for (int cp = 0; cp < 2; ++cp)
       for (int ip = 0; ip < C / CB; ++ip) pack_segment(s, w.data(), 1, 1, C, 96, ip * CB, CB, cp * 64, 64);
     e->heads_stream_off = add_stream(ar, s, e->heads_nms, 64);
-    FoldedBN g = fold_bn(ar, wf, "policy.gpool_bn");
+    FoldedBN g = fold_bn(ar, wf, "policy.gpool_bn", 32);
     e->head_off["gbn_scale"] = g.scale_off;
     e->head_off["gbn_shift"] = g.shift_off;
-    const char* names[] = {"policy.gpool_dense.w", "policy.gpool_dense.b", "policy.out_moves.w",
-                           "policy.out_pass.w", "policy.out_pass.b", "policy.opt_moves.w",
-                           "policy.opt_pass.w", "policy.opt_pass.b", "value.oq_embed.w",
-                           "value.oq_embed.b", "value.oq_out.w", "value.oq_out.b", "value.own.w",
-                           "value.gamma_pre.w", "value.gamma_pre.b", "value.gamma_out.w",
-                           "value.gamma_out.b", "value.score_pre.w", "value.score_pre.b",
-                           "value.score_out.w", "value.score_out.b"};
-    for (const char* n : names) {
-      const Tensor& t = wf.get(n);
-      e->head_off[n] = ar.add(t.data, t.size() * 4);
+    const size_t H = 32, V = (size_t)wf.V;
+    const struct { const char* name; size_t n; } heads[] = {   // sizes k_heads reads (kernels.h HeadsArgs)
+        {"policy.gpool_dense.w", 2 * H * H}, {"policy.gpool_dense.b", H}, {"policy.out_moves.w", 2 * H},
+        {"policy.out_pass.w", 4 * H}, {"policy.out_pass.b", 2}, {"policy.opt_moves.w", H},
+        {"policy.opt_pass.w", 2 * H}, {"policy.opt_pass.b", 1}, {"value.oq_embed.w", 2 * H * V},
+        {"value.oq_embed.b", V}, {"value.oq_out.w", V * 14}, {"value.oq_out.b", 14}, {"value.own.w", H},
+        {"value.gamma_pre.w", 2 * H * V}, {"value.gamma_pre.b", V}, {"value.gamma_out.w", V},
+        {"value.gamma_out.b", 1}, {"value.score_pre.w", (2 * H + 1) * V}, {"value.score_pre.b", V},
+        {"value.score_out.w", V}, {"value.score_out.b", 1}};
+    for (const auto& h : heads) {
+      const Tensor& t = wf.get(h.name, h.n);
+      e->head_off[h.name] = ar.add(t.data, t.size() * 4);
     }
+  }
+  if (!wf.missing.empty()) {
+    e->err = "weight file lacks tensors of the architecture its header names: " + wf.missing;
+    return false;
+  }
+  if (ar.bad_stream) {
+    e->err = "internal error: a packed weight stream is not a whole number of ring macro-steps";
+    return false;
   }
   return true;
 }
@@ -514,6 +542,9 @@ p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version
     return (p3hip_engine*)nullptr;
   };
   if (!e->wf.load(weights_path, e->err)) return fail(e->err);
+  // host-side plan first (weight repacking; no HIP call): a bad file fails here, GPU or not
+  Arena ar;
+  if (!build_plan(e, ar)) return fail(e->err);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_ordinal)
     return fail("no HIP device " + std::to_string(device_ordinal) + " (the HIP engine has no CPU fallback)");
@@ -523,8 +554,6 @@ p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
     return fail(std::string("device is ") + prop.gcnArchName + ", this engine is built for gfx950 only");
   e->n_cu = prop.multiProcessorCount;
-  Arena ar;
-  if (!build_plan(e, ar)) return fail(e->err);
   const int C = e->wf.C;
   const size_t B = batch_size;
   bool ok = e->check(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate") &&
@@ -551,6 +580,7 @@ p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version
 
 void p3hip_destroy(p3hip_engine* e) {
   if (!e) return;
+  if (e->stream || e->d_arena) (void)hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   hipFree(e->d_arena); hipFree(e->d_feats); hipFree(e->d_x); hipFree(e->d_t); hipFree(e->d_u);
   hipFree(e->d_hp); hipFree(e->d_out);
@@ -587,6 +617,7 @@ static int gather_loaded(p3hip_engine* e) {
 }
 
 int p3hip_upload(p3hip_engine* e) {
+  if (!e->bind()) return 1;
   int n = gather_loaded(e);
   if (n == 0) return 0;
   if (!e->check(hipMemcpyAsync(e->d_feats, e->h_feats_compact, (size_t)n * kFeatBytes,
@@ -595,13 +626,14 @@ int p3hip_upload(p3hip_engine* e) {
 }
 
 int p3hip_forward_resident(p3hip_engine* e, int n_positions) {
-  if (n_positions < 1 || n_positions > e->batch) return 1;
+  if (n_positions < 1 || n_positions > e->batch || !e->bind()) return 1;
   return enqueue_forward(e, n_positions) ? 0 : 1;
 }
 
-int p3hip_sync(p3hip_engine* e) { return e->check(hipStreamSynchronize(e->stream), "sync") ? 0 : 1; }
+int p3hip_sync(p3hip_engine* e) { return e->bind() && e->check(hipStreamSynchronize(e->stream), "sync") ? 0 : 1; }
 
 int p3hip_run(p3hip_engine* e) {
+  if (!e->bind()) return 1;
   int n = gather_loaded(e);
   if (n == 0) return 0;
   if (!e->check(hipMemcpyAsync(e->d_feats, e->h_feats_compact, (size_t)n * kFeatBytes,
@@ -631,6 +663,7 @@ int p3hip_get_ownership(p3hip_engine* e, int slot, float out[P3HIP_NUM_LOCS]) {
   if (slot < 0 || slot >= e->batch) return 1;
   int row = e->slots.row(slot);
   if (row < 0) return 2;
+  if (!e->bind()) return 1;
   if (!e->check(hipMemcpy(out, e->d_out + (size_t)row * p3::kOutStride + p3::kOffOwnership,
                           kNLoc * 4, hipMemcpyDeviceToHost), "D2H ownership")) return 1;
   e->slots.fetched(slot);
@@ -642,6 +675,7 @@ int p3hip_get_raw(p3hip_engine* e, int slot, float* out) {
   int row = e->slots.row(slot);
   if (row < 0) return 2;
   std::vector<float> rec(p3::kOutStride);
+  if (!e->bind()) return 1;
   if (!e->check(hipMemcpy(rec.data(), e->d_out + (size_t)row * p3::kOutStride, p3::kOutStride * 4,
                           hipMemcpyDeviceToHost), "D2H raw")) return 1;
   memcpy(out, rec.data() + p3::kOffMoveLogits, 362 * 4);
@@ -670,30 +704,6 @@ void p3hip_flops_per_position(const p3hip_engine* e, double* total, double* conv
   if (conv3x3) *conv3x3 = 2.0 * mac3;
 }
 
-// Diagnostic: runs the first btl block (C=256, L=3 only) with in-kernel phase stamps.
-// out receives grid*8*4*32 u64 (workgroup, wave, position index, stamp id).
-int p3hip_debug_block_stamps(p3hip_engine* e, int n_positions, unsigned long long* out, int max_u64) {
-  const WeightFile& wf = e->wf;
-  const BlockPlan* bp = nullptr;
-  for (const BlockPlan& b : e->blocks)
-    if (b.kind == 0) { bp = &b; break; }
-  if (!bp || wf.C != 256 || wf.inner != 3) { e->err = "stamps: need a C=256 btl3 net"; return 1; }
-  const int grid = grid_for(e, n_positions, 1);
-  const size_t n = (size_t)grid * 8 * 4 * 32;
-  if ((size_t)max_u64 < n) { e->err = "stamps: buffer too small"; return 1; }
-  unsigned long long* d = nullptr;
-  if (!e->check(hipMalloc((void**)&d, n * 8), "hipMalloc stamps")) return 1;
-  hipMemsetAsync(d, 0, n * 8, e->stream);
-  p3::BlockArgs a = block_args(e, (size_t)(bp - e->blocks.data()), 1, n_positions);
-  a.stamps = d;
-  a.dbg = getenv("P3HIP_DBG") ? atoi(getenv("P3HIP_DBG")) : 0;
-  bool ok = e->check(p3::launch_block_stamps(a, grid, e->stream), "launch stamps") &&
-            e->check(hipStreamSynchronize(e->stream), "sync") &&
-            e->check(hipMemcpy(out, d, n * 8, hipMemcpyDeviceToHost), "D2H stamps");
-  hipFree(d);
-  return ok ? grid : -1;
-}
-
 double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
                                double* flops_per_launch, const char** kernel_name) {
   const WeightFile& wf = e->wf;
@@ -701,7 +711,7 @@ double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
   int nfused = 0;
   for (const BlockPlan& b : e->blocks)
     if (b.kind == 0 || b.kind == 1) { if (!bp) bp = &b; ++nfused; }   // fused block kernel only
-  if (!bp || n_positions < 1 || n_positions > e->batch || iters < 1) return -1.0;
+  if (!bp || n_positions < 1 || n_positions > e->batch || iters < 1 || !e->bind()) return -1.0;
   // Time the kernel where it runs: whole forward passes over the resident batch, with a HIP
   // event pair (on the engine's stream) around each fused-block launch.  The average over all
   // launches is what rocprofv3 --kernel-trace --stats reports for the same run.

@@ -40,8 +40,6 @@ struct BlockArgs {
   int npos;
   int nblk;
   BlockParams blk[kMaxFuse];
-  unsigned long long* stamps;  // diagnostic build only
-  int dbg;                     // diagnostic build only
 };
 
 struct InitArgs {
@@ -112,7 +110,6 @@ struct HeadsArgs {
 };
 
 hipError_t launch_block(int C, int kind, int L, const BlockArgs& a, int grid, hipStream_t s);
-hipError_t launch_block_stamps(const BlockArgs& a, int grid, hipStream_t s);
 hipError_t launch_init(int C, const InitArgs& a, int grid, hipStream_t s);
 // which: 0 = broadcast conv_first (bn+mish prologue, mish epilogue), 1 = broadcast
 // conv_last (+residual), 2 = head convs (fp32 out, COUT = 96)

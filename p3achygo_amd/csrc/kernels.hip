@@ -25,17 +25,7 @@ namespace p3 {
 //   reduce: for each CB-slice of C input channels; inner 3x3 convs in order; expand: for
 //   each CB-slice of C output channels.
 // =======================================================================================
-// STAMPS: diagnostic build only (p3hip_debug_block_stamps): lane 0 of each wave of every
-// workgroup stores s_memtime at each phase boundary into a.stamps (never read by the kernel).
-#define P3_STAMP(k)                                                                          \
-  if (STAMPS) {                                                                              \
-    const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                         \
-    if ((threadIdx.x & 63) == 0 && npos_done < 4)                                            \
-      a.stamps[((blockIdx.x * 8 + w_) * 4 + npos_done) * 32 + (k)] =                         \
-          __builtin_amdgcn_s_memtime();                                                      \
-  }
-
-template <int C, int CB, int KIND, int L, bool STAMPS = false>
+template <int C, int CB, int KIND, int L>
 __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
   constexpr int NPOS = 128 / CB;
   using G = Geo<NPOS, CB, 3>;
@@ -47,21 +37,7 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
   act_zero<G>(smem);
   Ring<T::RS> ring;
   ring_init(ring, smem, a.blk[0].wstream, a.blk[0].nms_total, kRingOff);
-  if (STAMPS) ring.dbg = a.dbg;
   lds_barrier();
-#if (P3_EXP & 512)
-  if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger half
-#endif
-#if (P3_EXP & 1024)
-  if (threadIdx.x < 256) __builtin_amdgcn_s_setprio(1);    // experiment: ... for the older half
-#endif
-#if (P3_EXP & 64)
-  {   // stagger experiment: workgroup i starts (i % 8) * 3000 cycles late
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    const unsigned long long d = (unsigned long long)(blockIdx.x & 7) * 3000ull;
-    while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
-  }
-#endif
 
   static_assert(C / CB == 2, "two input slices / two output passes");
 #pragma unroll 1
@@ -84,7 +60,6 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
     // last position of a block that is not the last: the weight prefetch wraps into the next
     // block's stream instead of this block's start
     if (pos_next >= a.npos && blk + 1 < a.nblk) ring_retarget(ring, a.blk[blk + 1].wstream);
-    P3_STAMP(0);
     // ---- reduce 1x1 (C -> CB), prologue bn0+mish applied to the fetched slice in
     // registers; slice 1 is fetched under the slice-0 MFMAs -------------------------------
     stage_store<G, false>(smem, xr, 0, nullptr, nullptr);
@@ -94,30 +69,19 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
     // first position, the 12 output stores of the previous position's last pass (the 12
     // loads of the next-position prefetch issued before them are already consumed)
     ring_note_inflight(ring, npos_done == 0 ? 12 : 24);
-    P3_STAMP(1);
-    conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
-    P3_STAMP(2);
+    conv_segment16<G, CB, 1, 1>(ring, smem, acc);
     stage_math<G>(xr, G::NCH, bp.scale[0], bp.shift[0]);
     lds_barrier();
     stage_store<G, false>(smem, xr, G::NCH, nullptr, nullptr);
-    P3_STAMP(3);
-    conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
-    P3_STAMP(4);
+    conv_segment16<G, CB, 1, 1>(ring, smem, acc);
     if (KIND == 0) {
 #pragma unroll
       for (int j = 1; j <= L; ++j) {
         epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[j], bp.shift[j]);
         acc16_zero<NT>(acc);
-        P3_STAMP(3 + 2 * j);
-        conv_segment16<G, CB, 3, 9, STAMPS>(ring, smem, acc);
-        P3_STAMP(4 + 2 * j);
-        if (STAMPS && (threadIdx.x & 63) == 0 && npos_done < 4) {
-          const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-          a.stamps[((blockIdx.x * 8 + w_) * 4 + npos_done) * 32 + 20 + j] = ring.wait_cycles;
-        }
+        conv_segment16<G, CB, 3, 9>(ring, smem, acc);
       }
       epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[L + 1], bp.shift[L + 1]);
-      P3_STAMP(11);
     } else {
       // nbt: the raw inner residual stream t is parked in HBM scratch (fp16, as the reference's
       // fp16 engine keeps it) instead of 96 fp32 registers per lane: it is written once after
@@ -130,10 +94,10 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         acc16_zero<NT>(acc);
-        conv_segment16<G, CB, 3, 9, STAMPS>(ring, smem, acc);
+        conv_segment16<G, CB, 3, 9>(ring, smem, acc);
         epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[2 + 2 * r], bp.shift[2 + 2 * r]);
         acc16_zero<NT>(acc);
-        conv_segment16<G, CB, 3, 9, STAMPS>(ring, smem, acc);
+        conv_segment16<G, CB, 3, 9>(ring, smem, acc);
         // t is fetched after the K loop: holding it across the 3x3 loop costs more (spills of
         // the loaded values, i.e. the same exposed latency plus scratch traffic)
         residual_addr16<G, CB, NT>(tr, CB, pos0, a.npos, 0);
@@ -146,7 +110,6 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
     // ---- expand 1x1 (CB -> C) + residual, straight to HBM.  The residual of each output
     // pass is loaded before that pass's MFMAs (12 sixteen-byte loads/lane); in pass 1 the 12
     // stores of pass 0 are in flight as well ------------------------------------------------------
-    P3_STAMP(12);
     {
       // Pass 1's residual is requested before pass 0's output stores go out: vmcnt retires in
       // issue order, so loads issued behind the stores would also wait for the stores' acks.
@@ -155,25 +118,20 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
       residual_load16<NT>(rr0, a.x);
       ring_note_inflight(ring, 12);
       acc16_zero<NT>(acc);
-      conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
-      P3_STAMP(13);
+      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
       residual_addr16<G, CB, NT>(rr1, C, pos0, a.npos, CB);
       residual_load16<NT>(rr1, a.x);
       epilogue_store16<true, NT>(acc, rr0, a.x);
-      P3_STAMP(14);
       ring_note_inflight(ring, 24);
       acc16_zero<NT>(acc);
-      conv_segment16<G, CB, 1, 1, STAMPS>(ring, smem, acc);
-      P3_STAMP(15);
+      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
       // next position's first slice: issued once the last K loop of this position is over
       // (no fragment registers live), lands under the residual epilogue's stores
       stage_load<G>(xr, a.x, C, pos_next, a.npos, 0);
       epilogue_store16<true, NT>(acc, rr1, a.x);
-      P3_STAMP(16);
     }
     stage_math<G>(xr, 0, bp.scale[0], bp.shift[0]);   // next position's slice 0, before the barrier
     lds_barrier();
-    P3_STAMP(17);
   }
   }   // blocks
   ring_drain();
@@ -581,9 +539,7 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
         // two k16 steps ahead exactly as in the conv kernels.
         f32x16 acc2[2][1];
         acc_zero<GeoTt, 128>(acc2);
-#if !(P3_EXP & 2048)
-        conv_segment<GeoTt, 128, 1, 1, false, true>(ring, smem, acc2);
-#endif
+        conv_segment<GeoTt, 128, 1, 1, true>(ring, smem, acc2);
         if (!ct_active) continue;
         const f32x16 acc[2] = {acc2[0][0], acc2[1][0]};
         // epilogue: rows = channel (regs), cols = j (lanes)
@@ -610,11 +566,7 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
             half_swap32(o[0], o[1]);
             const h8 piece = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
             const int cb = (half * CH + ct * 32) / 8 + 2 * gp + h;   // this lane's channel block
-#if (P3_EXP & 4096)
-            asm volatile("" ::"v"(piece));
-#else
             *(h8*)(a.u + ((size_t)pos * (C / 8) + cb) * (kNLoc * 8) + j * 8) = piece;
-#endif
           }
         }
       }
@@ -927,16 +879,6 @@ static hipError_t launch_block_t(const BlockArgs& a, int grid, hipStream_t s) {
     attr_set = true;
   }
   hipLaunchKernelGGL((k_block<C, CB, KIND, L>), dim3(grid), dim3(kWG), lds, s, a);
-  return hipGetLastError();
-}
-
-hipError_t launch_block_stamps(const BlockArgs& a, int grid, hipStream_t s) {
-  using G = Geo<1, 128, 3>;
-  constexpr size_t lds = G::ACT_BYTES + ring_bytes(128);
-  hipError_t e = hipFuncSetAttribute((const void*)k_block<256, 128, 0, 3, true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_block<256, 128, 0, 3, true>), dim3(grid), dim3(kWG), lds, s, a);
   return hipGetLastError();
 }
 

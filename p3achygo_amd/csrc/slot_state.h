@@ -27,6 +27,7 @@ class SlotStates {
     for (auto& s : st_) s.store(kIdle, std::memory_order_relaxed);
   }
   int size() const { return (int)st_.size(); }
+  uint8_t state(int slot) const { return st_[slot].load(std::memory_order_acquire); }
   // LoadBatch: the features of `slot` have been written (release pairs with gather's acquire).
   void loaded(int slot) { st_[slot].store(kLoaded, std::memory_order_release); }
   // Start of a run: calls take(slot, row) for every dirty slot (every slot when `all`), in slot

@@ -27,10 +27,9 @@ EXPORTS = [
     "p3hip_create", "p3hip_create_error", "p3hip_destroy", "p3hip_kind", "p3hip_path",
     "p3hip_batch_size", "p3hip_load_slot", "p3hip_run", "p3hip_get_slot", "p3hip_get_ownership",
     "p3hip_last_error", "p3hip_forward_resident", "p3hip_upload", "p3hip_sync", "p3hip_get_raw",
-    "p3hip_time_trunk_kernel", "p3hip_flops_per_position", "p3hip_debug_block_stamps",
+    "p3hip_time_trunk_kernel", "p3hip_flops_per_position",
 ]
 
-FLAG_NO_GRAPH = 1
 FLAG_RUN_ALL_SLOTS = 2
 
 
@@ -83,7 +82,6 @@ def lib():
                                               C.POINTER(C.c_char_p)]
         L.p3hip_flops_per_position.argtypes = [C.c_void_p, C.POINTER(C.c_double),
                                                C.POINTER(C.c_double)]
-        L.p3hip_debug_block_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -179,13 +177,6 @@ class HipEngine:
         if ms < 0:
             raise EngineError("time_trunk_kernel: " + self._L.p3hip_last_error(self._h).decode())
         return ms, fl.value, (name.value or b"").decode()
-
-    def debug_block_stamps(self, n_positions: int) -> np.ndarray:
-        buf = np.zeros(256 * 8 * 4 * 32, np.uint64)
-        grid = self._L.p3hip_debug_block_stamps(self._h, n_positions, buf.ctypes.data, len(buf))
-        if grid <= 0:
-            raise EngineError("debug_block_stamps: " + self._L.p3hip_last_error(self._h).decode())
-        return buf[:grid * 8 * 4 * 32].reshape(grid, 8, 4, 32)
 
     def flops_per_position(self):
         t, c = C.c_double(0), C.c_double(0)

@@ -531,8 +531,9 @@ Grid Board::GetStonesWithLiberties(int liberties) const {
 // through full PlayMove legality (suicide, superko, pass-alive prohibition).  All choices are
 // any/all quantifiers over the candidate moves, so the verdict does not depend on visiting
 // order and this restatement is free to enumerate liberties its own way.
-constexpr long kLadderNodeBudget = 20000;
+std::atomic<long> g_ladder_budget{0};   // 0 = unbounded (reference-exact), see SetLadderNodeBudget
 thread_local long t_ladder_nodes = 0;
+thread_local long t_ladder_budget = 0;   // the process-wide budget, read once per call
 thread_local bool t_ladder_exhausted = false;
 std::atomic<long> g_ladder_calls{0}, g_ladder_nodes{0}, g_ladder_max{0}, g_ladder_exhausted{0};
 
@@ -576,11 +577,12 @@ struct LadderSolver {
   // moved (the opponent of color_to_move) and reads on.
   static bool Solve(Board& board, Color g_color, Color color_to_move, int root, int last_move, int depth) {
     if (depth > 300) return false;
-    // Work bound (not in the reference, whose only bound is the depth): the read-out is
-    // exponential on chaotic positions with many groups in atari (seconds per call), and one
-    // stalled game stalls the whole evaluation batch.  An exhausted budget reads as "not
-    // laddered", like the depth bound; real ladders resolve in well under 1 % of it.
-    if (++t_ladder_nodes > kLadderNodeBudget) { t_ladder_exhausted = true; return false; }
+    // Optional work bound (off by default; not in the reference, whose only bound is the depth):
+    // the read-out is exponential on chaotic positions with many groups in atari, and in a
+    // batched self-play host one stalled game stalls its whole evaluation batch.  An exhausted
+    // budget reads as "not laddered", like the depth bound.
+    ++t_ladder_nodes;
+    if (t_ladder_budget > 0 && t_ladder_nodes > t_ladder_budget) { t_ladder_exhausted = true; return false; }
     if (!MoveOk(board.PlayMove(AsLoc(last_move), Opp(color_to_move)))) return g_color != color_to_move;
     const int gid = board.gid_[root];
     if (gid < 0) return true;  // captured (not reachable through the reads below)
@@ -623,6 +625,7 @@ Grid Board::GetLadderedStones() const {
     Board copy = *this;
     t_ladder_nodes = 0;
     t_ladder_exhausted = false;
+    t_ladder_budget = g_ladder_budget.load(std::memory_order_relaxed);
     // the reference anchors the group by its root stone; any stone of it works since the
     // group can only grow while it is being read
     const bool laddered = LadderSolver::Solve(copy, g_color, Opp(g_color), p, l[0], 0);
@@ -641,6 +644,9 @@ Grid Board::GetLadderedStones() const {
   }
   return data;
 }
+
+void SetLadderNodeBudget(long nodes) { g_ladder_budget.store(nodes < 0 ? 0 : nodes, std::memory_order_relaxed); }
+long LadderNodeBudget() { return g_ladder_budget.load(std::memory_order_relaxed); }
 
 void LadderStats(long out[4]) {
   out[0] = g_ladder_calls.load(); out[1] = g_ladder_nodes.load(); out[2] = g_ladder_max.load(); out[3] = g_ladder_exhausted.load();

@@ -144,6 +144,12 @@ class Board {
 
 // ladder read-out statistics since process start: calls, nodes, max nodes of one call, budget hits
 void LadderStats(long out[4]);
+// Work bound of one ladder read-out in nodes; 0 (the default) = none, i.e. the reference's
+// behaviour, bounded by depth 300 only (cc/game/board.cc:780-783).  A positive budget is the
+// self-play throughput mode: a read-out that exhausts it reads "not laddered" (counted in
+// LadderStats), which can differ from the reference on chaotic positions.  Process-wide.
+void SetLadderNodeBudget(long nodes);
+long LadderNodeBudget();
 
 // cc/game/game.{h,cc}: a board plus the move list (five leading noop moves) and result.
 struct Move {

@@ -1,6 +1,9 @@
 // capi.cc — C entry points of libp3host.so used by the tests (ctypes) to drive the rules
 // engine, RNG, symmetry and feature extraction.  Not part of the engine ABI.
+#include <algorithm>
+#include <array>
 #include <cstring>
+#include <vector>
 
 #include "board.h"
 #include "features.h"
@@ -181,6 +184,146 @@ int p3host_tfrec_record(void* r, const int* moves, int n, float komi, const floa
 }
 uint32_t p3host_crc32c(const void* p, size_t n) { return Crc32c(p, n); }
 void p3host_ladder_stats(long* out) { LadderStats(out); }
+void p3host_set_ladder_budget(long nodes) { SetLadderNodeBudget(nodes); }
+long p3host_ladder_budget() { return LadderNodeBudget(); }
+}
+
+// ---- ladder read-out: exact mode vs an independent naive read-out vs the budgeted mode --------
+// The naive reader follows cc/game/board.cc:692-899 through the PUBLIC board API only (flood
+// fills over position(), boards copied by value at every ply), sharing nothing with
+// board.cc's LadderSolver (which walks the circular group lists and the liberty counters).
+namespace {
+struct NaiveLadder {
+  static void Flood(const Board& b, int p, std::vector<int>& stones, std::vector<int>& libs) {
+    const Grid& g = b.position();
+    const Color c = g[p];
+    std::array<uint8_t, kNumLocs> seen{};
+    stones.assign(1, p);
+    libs.clear();
+    seen[p] = 1;
+    for (size_t h = 0; h < stones.size(); ++h) {
+      const int s = stones[h], i = s / kBoardLen, j = s % kBoardLen;
+      const int nb[4] = {i > 0 ? s - kBoardLen : -1, i < kBoardLen - 1 ? s + kBoardLen : -1, j > 0 ? s - 1 : -1,
+                         j < kBoardLen - 1 ? s + 1 : -1};
+      for (int q : nb) {
+        if (q < 0 || seen[q]) continue;
+        if (g[q] == kEmpty) { seen[q] = 1; libs.push_back(q); }
+        else if (g[q] == c) { seen[q] = 1; stones.push_back(q); }
+      }
+    }
+  }
+  static bool Solve(Board board, Color g_color, Color to_move, int root, int last_move, int depth) {
+    if (depth > 300) return false;
+    if (!MoveOk(board.PlayMove(AsLoc(last_move), Opp(to_move)))) return g_color != to_move;
+    if (board.position()[root] == kEmpty) return true;
+    std::vector<int> stones, libs;
+    Flood(board, root, stones, libs);
+    if (g_color != to_move) {   // attacker: needs exactly two liberties to keep chasing
+      if (libs.size() > 2) return false;
+      if (libs.size() <= 1) return true;
+      return Solve(board, g_color, Opp(to_move), root, libs[0], depth + 1) ||
+             Solve(board, g_color, Opp(to_move), root, libs[1], depth + 1);
+    }
+    if (libs.size() > 1) return false;   // defender already out
+    if (!Solve(board, g_color, Opp(to_move), root, libs[0], depth + 1)) return false;   // extend
+    // or capture an adjacent attacker group that is in atari
+    std::vector<int> done;   // one stone of every enemy group handled
+    for (int s : stones) {
+      const int i = s / kBoardLen, j = s % kBoardLen;
+      const int nb[4] = {i > 0 ? s - kBoardLen : -1, i < kBoardLen - 1 ? s + kBoardLen : -1, j > 0 ? s - 1 : -1,
+                         j < kBoardLen - 1 ? s + 1 : -1};
+      for (int q : nb) {
+        if (q < 0 || board.position()[q] != Opp(g_color)) continue;
+        std::vector<int> es, el;
+        Flood(board, q, es, el);
+        if (el.size() != 1) continue;
+        bool dup = false;
+        for (int d : done) dup |= std::find(es.begin(), es.end(), d) != es.end();
+        if (dup) continue;
+        done.push_back(q);
+        if (!Solve(board, g_color, Opp(to_move), root, el[0], depth + 1)) return false;
+      }
+    }
+    return true;
+  }
+  static Grid Laddered(const Board& b) {
+    Grid out{};
+    std::array<uint8_t, kNumLocs> handled{};
+    for (int p = 0; p < kNumLocs; ++p) {
+      if (b.position()[p] == kEmpty || handled[p]) continue;
+      std::vector<int> stones, libs;
+      Flood(b, p, stones, libs);
+      for (int s : stones) handled[s] = 1;
+      if (libs.size() != 1) continue;
+      int empty_nb = 0;   // IsLaddered's pre-check: the liberty has three or more empty neighbours
+      {
+        const int s = libs[0], i = s / kBoardLen, j = s % kBoardLen;
+        const int nb[4] = {i > 0 ? s - kBoardLen : -1, i < kBoardLen - 1 ? s + kBoardLen : -1, j > 0 ? s - 1 : -1,
+                           j < kBoardLen - 1 ? s + 1 : -1};
+        for (int q : nb) empty_nb += q >= 0 && b.position()[q] == kEmpty;
+      }
+      if (empty_nb >= 3) continue;
+      const Color c = b.position()[p];
+      if (Solve(b, c, Opp(c), p, libs[0], 0))
+        for (int s : stones) out[s] = c;
+    }
+    return out;
+  }
+};
+}  // namespace
+
+extern "C" {
+// Uniformly random legal playouts (seeded), one position every `stride` moves from move
+// `first_move` on, `n_positions` in all.  out[0] = positions where the exact mode (no budget)
+// and the naive reader disagree on the ladder plane, out[1] = positions where the budgeted mode
+// (`budget` nodes) differs from the exact mode, out[2] = read-outs that exhausted the budget,
+// out[3] = largest node count of one exact read-out, out[4] = positions with a laddered stone,
+// out[5] = total exact read-outs.  max_exact_nodes > 0 skips the (exponential) naive read of
+// positions whose exact read-out took more nodes than that; out[6] counts those.
+void p3host_test_ladder_modes(int n_positions, uint64_t seed, long budget, int first_move, int stride,
+                              long max_exact_nodes, long* out) {
+  for (int i = 0; i < 7; ++i) out[i] = 0;
+  const long saved = LadderNodeBudget();
+  PRng prng(seed, seed ^ 0x9e3779b97f4a7c15ull, seed * 3 + 1, seed * 7 + 5);
+  int done = 0;
+  while (done < n_positions) {
+    Game game(7.5f, true);
+    Color c = kBlack;
+    int passes = 0;
+    for (int mv = 0; mv < 420 && done < n_positions && passes < 2; ++mv) {
+      Loc pick = kPassLoc;
+      for (int tries = 0; tries < 30; ++tries) {
+        const int idx = RandRange(prng, 0, kNumLocs);
+        if (game.IsValidMove(AsLoc(idx), c)) { pick = AsLoc(idx); break; }
+      }
+      passes = pick == kPassLoc ? passes + 1 : 0;
+      game.PlayMove(pick, c);
+      c = Opp(c);
+      if (mv < first_move || (mv - first_move) % stride != 0) continue;
+      long s0[4], s1[4];
+      SetLadderNodeBudget(0);
+      LadderStats(s0);
+      const Grid exact = game.board().GetLadderedStones();
+      LadderStats(s1);
+      out[5] += s1[0] - s0[0];
+      const long nodes = s1[1] - s0[1];
+      if (nodes > out[3]) out[3] = nodes;
+      bool any = false;
+      for (Color v : exact) any |= v != kEmpty;
+      out[4] += any;
+      if (max_exact_nodes > 0 && nodes > max_exact_nodes) ++out[6];
+      else if (NaiveLadder::Laddered(game.board()) != exact) ++out[0];
+      SetLadderNodeBudget(budget);
+      LadderStats(s0);
+      const Grid fast = game.board().GetLadderedStones();
+      LadderStats(s1);
+      out[2] += s1[3] - s0[3];
+      out[1] += fast != exact;
+      ++done;
+    }
+  }
+  SetLadderNodeBudget(saved);
+}
 }
 
 // ---- fork manager / init-state / move-selection tests ----------------------------------------

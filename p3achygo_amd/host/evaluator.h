@@ -4,6 +4,8 @@
 #pragma once
 #include <dlfcn.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -73,14 +75,27 @@ struct HipEvaluator final : Evaluator {
     if (eng) destroy(eng);
     if (lib) dlclose(lib);
   }
-  void Load(int slot, const p3hip_features& f) override { load(eng, slot, &f); }
+  // The reference's engines abort on any failure (CUDA_OK / CHECK, trt_engine.cc:27-35); the
+  // adapter over the status-returning C ABI does the same, loudly, instead of handing the
+  // search an uninitialised result.
+  [[noreturn]] void Fatal(const char* what, int slot, int rc) {
+    std::fprintf(stderr, "p3hip %s(slot %d) failed with status %d: %s\n", what, slot, rc,
+                 (eng && last_error) ? last_error(eng) : "");
+    std::abort();
+  }
+  void Load(int slot, const p3hip_features& f) override {
+    if (int rc = load(eng, slot, &f)) Fatal("load_slot", slot, rc);
+  }
   bool Run() override {
     if (run(eng) != 0) { err = last_error(eng); return false; }
     return true;
   }
-  void Get(int slot, p3hip_result& r) override { get(eng, slot, &r); }
+  void Get(int slot, p3hip_result& r) override {
+    if (int rc = get(eng, slot, &r)) Fatal("get_slot", slot, rc);
+  }
   void GetOwnership(int slot, float out[P3HIP_NUM_LOCS]) override {
-    if (get_own) get_own(eng, slot, out);
+    if (!get_own) Fatal("get_ownership (symbol missing)", slot, -1);
+    if (int rc = get_own(eng, slot, out)) Fatal("get_ownership", slot, rc);
   }
 };
 

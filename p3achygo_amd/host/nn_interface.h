@@ -24,6 +24,8 @@
 #include <chrono>
 #include <climits>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <list>
 #include <memory>
 #include <mutex>
@@ -300,8 +302,7 @@ class NNInterface final {
 
   void SignalLoadedAndBlockUntilReady(int tid) {   // nn_interface.h:295-312
     if (num_threads_ == 1) {
-      engine_->Run();
-      num_inferences_.fetch_add(1, std::memory_order_relaxed);
+      RunEngine();
       return;
     }
     {
@@ -342,6 +343,16 @@ class NNInterface final {
     if (num_threads_ > 1) infer_cv_.notify_all();
   }
 
+  // A failed RunInference is fatal, as in the reference (CUDA_OK / CHECK abort the process,
+  // trt_engine.cc:27-35): no worker may be handed a result of a run that did not happen.
+  void RunEngine() {
+    if (!engine_->Run()) {
+      std::fprintf(stderr, "NNInterface: engine RunInference failed\n");
+      std::abort();
+    }
+    num_inferences_.fetch_add(1, std::memory_order_relaxed);
+  }
+
   // ---- inference loop (nn_interface.cc:279-404) --------------------------------------------
   void InferLoop() {
     while (running_.load(std::memory_order_acquire)) Infer();
@@ -379,8 +390,7 @@ class NNInterface final {
     for (const ThreadInfo& t : info_) any_loaded |= t.loaded;
     if (!any_loaded) return;
 
-    engine_->Run();
-    num_inferences_.fetch_add(1, std::memory_order_relaxed);
+    RunEngine();
     for (ThreadInfo& t : info_) {
       if (t.registered && t.loaded) {   // slots loaded after Run() started wait for the next cycle
         t.res_ready.store(true, std::memory_order_release);

@@ -6,6 +6,7 @@
 #include <thread>
 #include <vector>
 
+#include "../csrc/slot_state.h"
 #include "nn_interface.h"
 
 using namespace p3;
@@ -62,6 +63,59 @@ struct CountingEvaluator final : Evaluator {
   std::vector<std::atomic<int>> buf_, result_gen_, load_gen_;
   std::atomic<bool> race_{false}, stale_{false}, wrong_slot_{false};
   std::atomic<long> loads_{0};
+};
+
+// ---- an evaluator with the HIP engine's hand-over rules ----------------------------------------
+// Like p3hip_run it evaluates only the dirty slots, compacted into dense rows (the engine's own
+// SlotStates, csrc/slot_state.h), and its Run() takes a while with the interface lock held, so
+// worker loads land while it is gathering and running — the interleaving of
+// cc/nn/nn_interface.cc:351-361, in which a load is picked up by run N but only counted as loaded
+// for run N+1.  Get() checks that the slot was evaluated by the last run (bit 16), from the
+// features of its latest load (stale, bit 2), into the right row (wrong slot, bit 4).
+struct CompactingEvaluator final : Evaluator {
+  explicit CompactingEvaluator(int n, int run_us)
+      : n_(n), run_us_(run_us), slots_(n), load_seq_(n), row_seq_(n), row_val_(n) {
+    for (auto& a : load_seq_) a.store(0);
+  }
+  void Load(int t, const p3hip_features&) override {
+    load_seq_[t].fetch_add(1, std::memory_order_relaxed);   // "writes the features"
+    slots_.loaded(t);
+  }
+  bool Run() override {
+    const int n = slots_.gather(false, [&](int s, int row) {
+      if (slots_.state(s) == SlotStates::kEvaluated) ++reevaluated_;
+      row_seq_[row] = load_seq_[s].load(std::memory_order_relaxed);   // "copies the features"
+      row_val_[row] = -1;
+      if ((s & 7) == 0) std::this_thread::yield();   // stretch the gather: loads land inside it
+    });
+    std::this_thread::sleep_for(std::chrono::microseconds(run_us_));   // the forward pass
+    for (int s = 0; s < n_; ++s)
+      if (slots_.row(s) >= 0) row_val_[slots_.row(s)] = SlotFn(s);
+    rows_ += n;
+    ++runs_;
+    return true;
+  }
+  void Get(int t, p3hip_result& r) override {
+    std::memset(&r, 0, sizeof r);
+    const int row = slots_.row(t);
+    if (row < 0) {
+      unevaluated_ = true;
+      return;
+    }
+    if (row_seq_[row] != load_seq_[t].load(std::memory_order_relaxed)) stale_ = true;
+    if (row_val_[row] != SlotFn(t)) wrong_slot_ = true;
+    for (float& x : r.move_logits) x = (float)row_val_[row];
+    slots_.fetched(t);
+  }
+  int failures() const { return (stale_ ? 2 : 0) | (wrong_slot_ ? 4 : 0) | (unevaluated_ ? 16 : 0); }
+
+  const int n_, run_us_;
+  SlotStates slots_;
+  std::vector<std::atomic<long>> load_seq_;
+  std::vector<long> row_seq_;
+  std::vector<int> row_val_;
+  std::atomic<bool> stale_{false}, wrong_slot_{false}, unevaluated_{false};
+  long rows_ = 0, runs_ = 0, reevaluated_ = 0;
 };
 
 // One worker of the reference's stress loop: jitter, occasional long sleeps (every 8th
@@ -126,6 +180,73 @@ int p3host_test_nn_sync(int strategy, int num_threads, int millis, int cache_siz
   }
   if (calls_out) *calls_out = calls.load();
   return mask;
+}
+
+// The same stress loop over the compacting evaluator (the engine's slot rules).  Failure mask:
+// 2 stale, 4 wrong slot, 8 worker saw a wrong value, 16 a result was requested for a slot the
+// last run had not evaluated.  *rows_out / *runs_out = rows evaluated / runs.
+int p3host_test_nn_compacting(int strategy, int num_threads, int millis, int timeout_us, int run_us, long* calls_out,
+                              long* rows_out, long* runs_out) {
+  auto* ev = new CompactingEvaluator(num_threads, run_us);
+  std::atomic<bool> stop{false}, error{false};
+  std::atomic<long> calls{0};
+  int mask = 0;
+  {
+    NNInterface nn(num_threads, timeout_us, 0, std::unique_ptr<Evaluator>(ev), (NNInterface::WakeStrategy)strategy);
+    std::vector<std::thread> workers;
+    for (int t = 0; t < num_threads; ++t) workers.emplace_back(StressWorker, t, &nn, &nn, &stop, &error, &calls);
+    std::this_thread::sleep_for(std::chrono::milliseconds(millis));
+    stop.store(true);
+    for (auto& w : workers) w.join();
+    mask = ev->failures() | (error.load() ? 8 : 0);
+    if (rows_out) *rows_out = ev->rows_;
+    if (runs_out) *runs_out = ev->runs_;
+  }
+  if (calls_out) *calls_out = calls.load();
+  return mask;
+}
+
+// Deterministic replay of the hand-over sequences on the engine's SlotStates.  Returns 0, or the
+// number of the first step that went wrong.
+int p3host_test_slot_states() {
+  SlotStates st(8);
+  std::vector<int> rows;
+  auto run = [&](int load_during = -1, int when = -1) {
+    rows.clear();
+    return st.gather(false, [&](int s, int) {
+      rows.push_back(s);
+      if (s == when) st.loaded(load_during);   // a LoadBatch landing while the run gathers
+    });
+  };
+  st.loaded(2);
+  st.loaded(5);
+  if (run() != 2 || rows != std::vector<int>{2, 5} || st.row(2) != 0 || st.row(5) != 1 || st.row(3) != -1) return 1;
+  st.fetched(2);
+  // 5 was evaluated but its caller has not been handed the result yet (NNInterface counted its
+  // load for the next run): the next run must evaluate it again; 2 was fetched and is out
+  if (run() != 1 || rows != std::vector<int>{5} || st.row(5) != 0 || st.row(2) != -1) return 2;
+  st.fetched(5);
+  if (run() != 0 || st.row(5) != -1) return 3;
+  // a load that lands BEFORE the gather reaches its slot is evaluated by this run and stays
+  // dirty for the next one (the sequence of nn_interface.cc:351-361)
+  st.loaded(1);
+  if (run(6, 1) != 2 || rows != std::vector<int>{1, 6}) return 4;
+  st.fetched(1);
+  if (run() != 1 || rows != std::vector<int>{6}) return 5;
+  st.fetched(6);
+  // a load that lands AFTER the gather passed its slot waits for the next run
+  st.loaded(4);
+  if (run(0, 4) != 1 || rows != std::vector<int>{4} || st.row(0) != -1) return 6;
+  st.fetched(4);
+  if (run() != 1 || rows != std::vector<int>{0}) return 7;
+  // a reload of an evaluated-but-unfetched slot is a fresh load
+  st.loaded(0);
+  if (run() != 1 || rows != std::vector<int>{0}) return 8;
+  st.fetched(0);
+  // RUN_ALL_SLOTS evaluates everything and leaves the states alone
+  if (st.gather(true, [](int, int) {}) != 8 || st.row(7) != 7) return 9;
+  if (run() != 0) return 10;
+  return 0;
 }
 
 // The async path parallel search uses (nn_interface.h:176-198, search.cc's SearchTask):

@@ -182,6 +182,24 @@ def set_policy(init_state_sampling: bool = True, use_seen_state_prob: float = 0.
     L.p3host_selfplay_set_policy(int(init_state_sampling), use_seen_state_prob, sel_mult_base, sel_mult_scale_factor)
 
 
+def set_ladder_budget(nodes: int) -> None:
+    """Work bound of one ladder read-out (process-wide).  0, the default, is the reference's
+    behaviour (depth bound only, cc/game/board.cc:780-783): planes 13/14 bit-exact.  A positive
+    budget is the opt-in throughput mode of the self-play host: an exhausted read-out reads "not
+    laddered" and is counted (ladder_stats()[3])."""
+    L = lib()
+    L.p3host_set_ladder_budget.argtypes = [C.c_long]
+    L.p3host_set_ladder_budget(int(nodes))
+
+
+def ladder_stats():
+    """(read-outs, nodes, max nodes of one read-out, budget hits) since process start."""
+    L = lib()
+    out = (C.c_long * 4)()
+    L.p3host_ladder_stats(out)
+    return tuple(out)
+
+
 def set_groups(n: int) -> None:
     """Game groups (engine instances) of subsequent selfplay_run calls; default 2."""
     L = lib()

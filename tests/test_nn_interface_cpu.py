@@ -19,6 +19,7 @@ def L(built):
     lib = host_api.lib()
     lib.p3host_test_nn_sync.argtypes = [C.c_int] * 5 + [C.c_void_p]
     lib.p3host_test_nn_async.argtypes = [C.c_int] * 4 + [C.c_void_p]
+    lib.p3host_test_nn_compacting.argtypes = [C.c_int] * 5 + [C.c_void_p] * 3
     lib.p3host_nn_new.restype = C.c_void_p
     lib.p3host_nn_new.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int,
                                   C.c_char_p, C.c_int]
@@ -46,6 +47,27 @@ def test_sync_no_race_no_stale_no_mixup(L, strategy, cache):
     mask = L.p3host_test_nn_sync(strategy, 128, 2500, cache, 0, C.byref(calls))
     assert mask == 0, f"failure mask {mask:#x} (1 race, 2 stale, 4 wrong slot, 8 wrong value)"
     assert calls.value > 128 * 20     # the interface made progress on every thread's behalf
+
+
+def test_engine_slot_states_hand_over_rules(L):
+    """The engine's dirty-slot rules (csrc/slot_state.h), replayed step by step: a slot stays in
+    the run set until its result is fetched, so the load-during-run interleaving of
+    nn_interface.cc:351-361 (picked up by run N, counted for run N+1) still yields a result."""
+    assert L.p3host_test_slot_states() == 0
+
+
+@pytest.mark.parametrize("strategy", [MUTEX, GEN_COUNTER])
+def test_sync_over_a_compacting_engine(L, strategy):
+    """The stress loop over an evaluator with the HIP engine's compaction rules whose Run() takes
+    300 us with the interface lock held while workers keep loading, 100 us batch timeout: every
+    result handed out was evaluated by the last run, from the caller's latest load, in its slot."""
+    calls, rows, runs = C.c_long(0), C.c_long(0), C.c_long(0)
+    mask = L.p3host_test_nn_compacting(strategy, 64, 2500, 100, 300, C.byref(calls), C.byref(rows), C.byref(runs))
+    assert mask == 0, f"failure mask {mask:#x} (2 stale, 4 wrong slot, 8 wrong value, 16 slot not evaluated)"
+    assert calls.value > 64 * 20 and runs.value > 100
+    # every call was evaluated at least once; the evaluator stretches its gather with yields to
+    # provoke loads landing inside it, each of which costs one re-evaluated row in the next run
+    assert rows.value >= calls.value
 
 
 @pytest.mark.parametrize("strategy", [MUTEX, GEN_COUNTER])

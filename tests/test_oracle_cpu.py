@@ -211,3 +211,38 @@ def test_engine_fails_loudly_without_gpu(built, weight_files):
     from p3achygo_amd import engine
     with pytest.raises(engine.EngineError):
         engine.HipEngine(weight_files("test_b3c128btl2"), 4)
+
+
+def test_bad_weight_files_fail_creation_with_a_message(built, weight_files, tmp_path):
+    """A truncated file, a file whose header names an architecture its tensor table lacks, and a
+    mis-shaped tensor all fail p3hip_create with a message (the library never aborts the host);
+    the weight plan is built before any HIP call, so this holds with and without a GPU."""
+    from p3achygo_amd import engine, netspec
+    good = open(weight_files("test_b3c128btl2"), "rb").read()
+    cut = tmp_path / "cut.p3w"
+    cut.write_bytes(good[:len(good) // 2])
+    with pytest.raises(engine.EngineError, match="truncated"):
+        engine.HipEngine(str(cut), 4)
+    cfg = netspec.CONFIGS["test_b3c128btl2"]
+    W = netspec.generate_weights(cfg)
+    # header says 3 blocks, table holds the tensors of a 2-block net: blocks.2.* are missing
+    cfg2 = netspec.NetConfig("two", 2, 128, 64, 32, 32, 3, 2, "btl")
+    W2 = netspec.generate_weights(cfg2)
+    p = tmp_path / "short.p3w"
+    netspec.save_p3w(str(p), cfg2, W2)
+    blob = bytearray(p.read_bytes())
+    blob[8:12] = (3).to_bytes(4, "little")          # nblocks field of the header
+    p.write_bytes(bytes(blob))
+    with pytest.raises(engine.EngineError, match=r"lacks tensors.*blocks\.2\."):
+        engine.HipEngine(str(p), 4)
+    # a tensor of the wrong size
+    Wbad = dict(W)
+    p3 = tmp_path / "shape.p3w"
+    specs = netspec.tensor_specs(cfg)
+    netspec.save_p3w(str(p3), cfg, Wbad)
+    blob = bytearray(p3.read_bytes())
+    ent0 = 44 + [n for n, _, _ in specs].index("policy.conv_p.w") * 76
+    blob[ent0 + 52 + 12:ent0 + 52 + 16] = (16).to_bytes(4, "little")   # dims[3]: 32 -> 16
+    p3.write_bytes(bytes(blob))
+    with pytest.raises(engine.EngineError, match=r"policy\.conv_p\.w \(wrong size\)"):
+        engine.HipEngine(str(p3), 4)

@@ -215,3 +215,35 @@ def test_pass_alive_update_points(host):
     b.pass_(1)                                # third pass overall -> Benson runs
     assert (b.pass_alive()[0:2, 0:4] == 1).all()
     assert b.dry_status(0, 0, 1) == 4         # kPassAliveRegion
+
+
+def test_ladder_readout_exact_mode_equals_naive_reader_and_budget_is_a_switch(built):
+    """Planes 13/14 (Board::GetLadderedStones, cc/game/board.cc:692-899).  Default mode = the
+    reference's (depth bound only): over 20,000 random-playout positions it agrees, bit for bit,
+    with an independent naive read-out written against the public board API (flood fills, boards
+    copied by value).  The node budget is an opt-in throughput mode of the self-play host
+    (host_api.set_ladder_budget): off by default, and with 20,000 nodes it never fires on this
+    position distribution (it does on search-tree positions: its hits are counted in
+    ladder_stats and reported by bench.py)."""
+    import ctypes as C
+    from p3achygo_amd import host_api
+    L = host_api.lib()
+    L.p3host_ladder_budget.restype = C.c_long
+    assert L.p3host_ladder_budget() == 0                      # reference-exact unless asked otherwise
+    L.p3host_test_ladder_modes.argtypes = [C.c_int, C.c_uint64, C.c_long, C.c_int, C.c_int, C.c_long, C.c_void_p]
+    out = (C.c_long * 7)()
+    L.p3host_test_ladder_modes(20000, 11, 20000, 10, 1, 0, out)
+    naive_diff, budget_diff, budget_hits, max_nodes, with_ladder, readouts, skipped = list(out)
+    assert naive_diff == 0 and skipped == 0
+    assert budget_diff == 0 and budget_hits == 0 and max_nodes < 20000
+    assert with_ladder > 5000 and readouts > 100000             # the sample is not vacuous
+    # a budget small enough to fire changes planes (so the switch is live) and is counted
+    L.p3host_test_ladder_modes(3000, 12, 40, 60, 1, 0, out)
+    assert out[0] == 0 and out[2] > 0 and out[1] > 0
+    assert L.p3host_ladder_budget() == 0                      # restored
+    before = host_api.ladder_stats()
+    host_api.set_ladder_budget(25)
+    L.p3host_ladder_budget.restype = C.c_long
+    assert L.p3host_ladder_budget() == 25
+    host_api.set_ladder_budget(0)
+    assert host_api.ladder_stats()[0] == before[0]

@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: b12c256btl3 policy/value-net evaluation of leaf positions.
+"""Benchmark of the hot path: b12c256btl3 self-play, leaf positions evaluated per second.
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the engine's forward path (init conv -> 12 residual blocks ->
-heads) over one batch of 1024 synthetic 19x19 positions per GPU (BASELINE.json configs[2]:
-"v3-b12c256btl3 on 1 MI355X, 1024 concurrent games, batch=1024, fp16"), inputs already
-resident in HBM when the timed region starts.  Games shard embarrassingly across GPUs
-(one engine + one HIP stream per device, no collective on the data path), so scaling is
-weak: every rank evaluates its own 1024 positions.
+Headline (BASELINE.json metric): leaf positions evaluated per second through
+`p3hip_run` while the C++ self-play host (libp3host.so: Gumbel MCTS n=32, thousands of concurrent
+19x19 games) drives the HIP engine through its C ABI — host search + PCIe + engine, random-init
+b12c256btl3 weights, 1024 positions per engine batch (BASELINE.json configs[2]).  One "step" = one
+engine batch (`p3hip_run` over one group of 1024 games' leaf positions); the host keeps GROUPS
+groups in flight (GROUPS - 1 forward passes queued on the GPU while one group is on the host).
+W warm-up rounds (one batch per group each) run untimed, then exactly K steps are timed inside the
+host (its own steady clock around the rounds, engine streams drained at the end), bracketed by
+barriers; the slowest rank's time is the job's time.  Games shard embarrassingly across GPUs (one
+process, one engine set, one HIP stream set per device; no data-path collective): weak scaling.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel k_block: conv FLOPs (3x3s + 1x1 reduce/expand) per
-launch / HIP-event time, against the 2.5 PFLOP/s dense fp16 MFMA peak) and `cpu_baseline`
-(the CPU fp32 oracle timed on this box's host cores over a bounded sample).
+Secondary figures in the same JSON line:
+  engine_only  — forward pass alone over a resident batch (no host, no PCIe);
+  roofline     — dominant kernel k_block: conv FLOPs (3x3s + 1x1 reduce/expand) per launch / HIP-event
+                 time on the engine's stream, against the 2.5 PFLOP/s dense fp16 MFMA peak;
+  cpu_baseline — the CPU fp32 oracle on this box's host cores over a bounded sample: engine-only
+                 (`value`), and behind the same self-play host through the same C ABI (`selfplay`).
 """
 import argparse
 import json
@@ -28,7 +35,9 @@ import numpy as np  # noqa: E402
 
 MODEL = "b12c256btl3"
 BATCH = 1024
+GROUPS = 4          # game groups per GPU: 3 forward passes queued while the 4th group is on the host
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 PF
+LADDER_BUDGET = 20000   # self-play throughput mode of the ladder read-out (host_api.set_ladder_budget)
 
 
 def make_positions(n, seed):
@@ -38,10 +47,11 @@ def make_positions(n, seed):
     return np.tile(base, reps)[:n].copy()
 
 
-def cpu_baseline(path, pos, budget_s=12.0):
+def cpu_baseline(path, pos, model, budget_s=10.0):
     """CPU fp32 oracle (oracle/nn_oracle.c, a port: the reference TF-CPU engine is stale and
-    unbuildable) on all host cores, bounded to ~budget_s seconds."""
+    unbuildable) on the host cores, bounded to ~budget_s seconds per leg."""
     from oracle import oracle
+    from p3achygo_amd import host_api
     # the GPU box gives a 1-GPU job a 16-CPU share; never oversubscribe it
     cores = min(len(os.sched_getaffinity(0)), 16)
     net = oracle.OracleNet(path)
@@ -54,36 +64,61 @@ def cpu_baseline(path, pos, budget_s=12.0):
     t0 = time.perf_counter()
     net.forward_features(sample, nthreads=cores)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "positions/s", "cores": cores, "kind": "port",
-            "sample": f"{n} positions of the same batch, {MODEL} fp32 direct conv, {dt:.1f}s"}
+    out = {"value": n / dt, "unit": "positions/s", "cores": cores, "kind": "port",
+           "what": "engine only: CPU fp32 oracle forward pass, no search",
+           "sample": f"{n} positions of the same batch, {model} fp32 direct conv, {dt:.1f}s"}
+    # the same self-play host, the CPU engine bound through the same C ABI:
+    # 2 groups x 4*cores games; the engine's forward pass gets all cores while a group is evaluated
+    try:
+        cpu_lib = os.path.join(ROOT, "oracle", "libp3cpu_engine.so")
+        os.environ["P3CPU_THREADS"] = str(cores)
+        games = 2 * 4 * cores
+        per_batch_s = (games / 2) / max(out["value"], 1e-9)
+        rounds = max(2, int(budget_s / max(2 * per_batch_s, 1e-3)))
+        host_api.set_groups(2)
+        host_api.set_step_limit(2 * rounds)
+        st = host_api.selfplay_run(path, games, cores, 0.0, default_n=32, default_k=5, selected_n=32, selected_k=5,
+                                   warmup_batches=1, seed=77, engine_lib=cpu_lib)
+        out["selfplay"] = {"value": st.positions / st.seconds, "unit": "positions/s", "cores": cores,
+                           "what": "the same self-play host (Gumbel n=32) over the CPU fp32 engine through the "
+                                   "same C ABI (oracle/libp3cpu_engine.so)",
+                           "sample": f"{games} concurrent games, {st.batches} engine batches of {games // 2}, "
+                                     f"{st.positions} positions, {st.seconds:.1f}s"}
+    except Exception as ex:   # noqa: BLE001
+        out["selfplay"] = {"error": repr(ex)}
+    finally:
+        host_api.set_step_limit(0)
+    return out
 
 
 def hbm_traffic(kernel_name, positions):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied; see
-    profiles/r01_hbm_fetch_write_pmc.txt).  PMC collection needs the profiler around the whole
-    process, so the number is a recorded measurement of this kernel at this batch size, not
-    re-measured inside the timed run; null when the profile does not match."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_k_block_hbm_traffic.json")) as f:
-            prof = json.load(f)
-    except OSError:
-        return None
-    if prof.get("kernel") != kernel_name or prof.get("positions_per_launch") != positions:
-        return None
-    return prof
+    --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied).  PMC collection
+    needs the profiler around the whole process, so the number is a RECORDED measurement of this
+    kernel at this batch size, not re-measured inside the timed run; null when no profile of this
+    build's kernel matches."""
+    for name in ("r02_k_block_hbm_traffic.json",):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                prof = json.load(f)
+        except OSError:
+            continue
+        if prof.get("kernel") == kernel_name and prof.get("positions_per_launch") == positions:
+            return prof
+    return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=4096, help="timed engine batches (p3hip_run calls) per GPU")
+    ap.add_argument("--warmup", type=int, default=16, help="untimed warm-up rounds (one batch per game group each)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--model", default=MODEL)
+    ap.add_argument("--engine-steps", type=int, default=200, help="timed steps of the engine-only leg")
+    ap.add_argument("--ladder-budget", type=int, default=LADDER_BUDGET,
+                    help="ladder read-out work bound of the self-play host (0 = reference-exact)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-selfplay", action="store_true")
-    ap.add_argument("--selfplay-seconds", type=float, default=8.0)
     args = ap.parse_args()
 
     from p3achygo_amd import sharding
@@ -94,69 +129,64 @@ def main():
     import torch
     sharding.init(shard)
     n_gpus = max(world, 1)
+    # host cores of this rank: its share of the allowed cores, on its GPU's NUMA node when known
+    bus_ids = None
+    try:
+        bus_ids = []
+        for d in range(torch.cuda.device_count()):
+            p = torch.cuda.get_device_properties(d)
+            bus_ids.append(f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0")
+    except Exception:   # noqa: BLE001
+        bus_ids = None
+    cpus = sharding.bind_rank_to_local_cpus(shard, bus_ids)
 
-    from p3achygo_amd import engine, netspec
+    from p3achygo_amd import engine, host_api, netspec
     cfg = netspec.CONFIGS[args.model]
     tmp = tempfile.mkdtemp(prefix="p3bench")
     path = os.path.join(tmp, f"{args.model}.p3w")
     netspec.save_p3w(path, cfg, netspec.generate_weights(cfg))  # fresh-Keras random init
     pos = make_positions(args.batch, seed=1000 + rank)
-
     torch.cuda.set_device(local_rank)
-    eng = engine.create_engine(engine.kind_from_engine_path(path), path, args.batch, 1,
-                               device=local_rank)
-    eng.load_all(pos)
-    eng.upload()  # inputs resident in HBM before the timed region
 
-    def barrier():
-        eng.sync()
-        torch.cuda.synchronize()
-        sharding.barrier(shard)
-
-    for _ in range(args.warmup):
-        eng.forward_resident(args.batch)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.forward_resident(args.batch)
-    eng.sync()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = sharding.max_over_ranks(shard, dt)
+    # ---- headline: self-play through the C ABI ----------------------------------------------
+    threads = max(2, min(16, len(cpus)))
+    steps = ((args.steps + GROUPS - 1) // GROUPS) * GROUPS     # whole rounds
+    host_api.set_groups(GROUPS)
+    host_api.set_ladder_budget(args.ladder_budget)
+    host_api.set_step_limit(steps)
+    ladder0 = host_api.ladder_stats()
     sharding.barrier(shard)
+    torch.cuda.synchronize()
+    wall0 = time.perf_counter()
+    st = host_api.selfplay_run(path, GROUPS * args.batch, threads, 0.0, default_n=32, default_k=5, selected_n=32,
+                               selected_k=5, warmup_batches=args.warmup, seed=sharding.seed_for_rank(77, shard),
+                               device=local_rank)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - wall0
+    host_api.set_step_limit(0)
+    ladder1 = host_api.ladder_stats()
+    dt = sharding.max_over_ranks(shard, st.seconds)
+    sharding.barrier(shard)
+    totals = sharding.sum_over_ranks(shard, [st.positions, st.moves, st.games, st.batches, st.cache_hits,
+                                             ladder1[0] - ladder0[0], ladder1[3] - ladder0[3]])
 
-    total_flops, conv3_flops = eng.flops_per_position()
-    eng.close()
-
-    # ---- the same engine driven by the real self-play host (PCIe-inclusive; reported
-    # beside `value`, never as `value`): 2 x batch concurrent games, Gumbel n=32 ----------
-    selfplay = None
-    if not args.no_selfplay:
-        from p3achygo_amd import host_api
-        cpus = len(os.sched_getaffinity(0))
-        threads = max(2, min(16, cpus // max(world, 1)))
-        GROUPS = 4   # game groups: three forward passes queued on the GPU while one group is on the host
-        host_api.set_groups(GROUPS)
-        rates, sp_err, secs = [0.0, 0.0], None, 0.0
-        try:   # a side measurement must never cost the headline line
-            st = host_api.selfplay_run(path, GROUPS * args.batch, threads, args.selfplay_seconds, default_n=32,
-                                       default_k=5, selected_n=32, selected_k=5, warmup_batches=4 * GROUPS,
-                                       seed=sharding.seed_for_rank(77, shard), device=local_rank)
-            rates, secs = [st.positions / st.seconds, st.moves / st.seconds], st.seconds
-        except Exception as ex:   # noqa: BLE001
-            sp_err = repr(ex)
-        sp = sharding.sum_over_ranks(shard, rates)
-        selfplay = {"value": float(sp[0]), "unit": "positions/s", "moves_per_s": float(sp[1]),
-                    "concurrent_games_per_gpu": GROUPS * args.batch, "batch": args.batch, "game_groups": GROUPS,
-                    "host_threads_per_gpu": threads, "seconds": secs,
-                    "gumbel": "n=32 (default k<=5, selected k=5)", "includes": "host MCTS + PCIe + engine"}
-        if sp_err:
-            selfplay["error"] = sp_err
+    # ---- secondary: the engine alone over a resident batch ----------------------------------
     eng = engine.create_engine(engine.kind_from_engine_path(path), path, args.batch, 1, device=local_rank)
     eng.load_all(pos)
     eng.upload()
-    eng.forward_resident(args.batch)
+    for _ in range(5):
+        eng.forward_resident(args.batch)
     eng.sync()
+    sharding.barrier(shard)
+    t0 = time.perf_counter()
+    for _ in range(args.engine_steps):
+        eng.forward_resident(args.batch)
+    eng.sync()
+    torch.cuda.synchronize()
+    dt_e = sharding.max_over_ranks(shard, time.perf_counter() - t0)
+    sharding.barrier(shard)
+    total_flops, conv3_flops = eng.flops_per_position()
+
     roof = None
     cpu = None
     if rank == 0:
@@ -166,37 +196,50 @@ def main():
         roof = {"bound": "mfma", "kernel": kname, "achieved": achieved,
                 "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP16_MFMA_TFLOPS,
-                "traffic": prof["traffic_bytes_per_launch"] if prof else None,   # HBM bytes per launch
+                "traffic": prof["traffic_bytes_per_launch"] if prof else None,   # HBM bytes per launch (recorded)
                 "launch_ms": ms, "algorithmic_flops_per_launch": flops_launch}
         if prof:
             roof["algorithmic_bytes_per_launch"] = prof["algorithmic_bytes_per_launch"]
-            roof["traffic_source"] = prof["source"]
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            try:
-                cpu = cpu_baseline(path, pos)
-            except Exception as ex:   # noqa: BLE001
-                cpu = {"error": repr(ex)}
+            roof["traffic_source"] = "recorded: " + prof["source"]
+    eng.close()
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(path, pos, args.model)
+        except Exception as ex:   # noqa: BLE001
+            cpu = {"error": repr(ex)}
     sharding.barrier(shard)
 
     if rank == 0:
-        pps = n_gpus * args.batch * args.steps / dt
+        pps = totals[0] / dt
+        eng_pps = n_gpus * args.batch * args.engine_steps / dt_e
         out = {
             "metric": "self-play positions/sec at 1/8 MI355X, b12c256btl3 19x19 n=32",
-            "value": pps, "unit": "positions/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "value": pps, "unit": "positions/s", "n_gpus": n_gpus, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{args.model} random-init, NN evaluation of {args.batch} "
-                                   "leaf positions per GPU per step (engine forward, inputs "
-                                   "resident in HBM; leaf positions from seeded random-legal "
-                                   "playouts)",
-                       "batch_per_gpu": args.batch, "parallelism": f"games sharded x{n_gpus}, no collective"},
-            "full_net_tflops": pps * total_flops / 1e12,
+            "config": {"workload": f"{args.model} random-init, self-play: C++ host (Gumbel MCTS n=32, default k<=5, "
+                                   f"selected k=5) -> p3hip_run over batches of {args.batch} leaf positions -> "
+                                   "results back to the search; one step = one engine batch",
+                       "batch_per_gpu": args.batch, "concurrent_games_per_gpu": GROUPS * args.batch,
+                       "game_groups_per_gpu": GROUPS, "host_threads_per_gpu": threads,
+                       "host_cpus_of_rank0": [cpus[0], cpus[-1]] if cpus else None,
+                       "ladder_node_budget": args.ladder_budget,
+                       "parallelism": f"games sharded x{n_gpus}, no collective"},
+            "includes": "host MCTS + PCIe (1,860 B up / 7,556 B down per position) + engine",
+            "positions": totals[0], "moves_per_s": totals[1] / dt, "finished_games": totals[2],
+            "engine_batches_completed": totals[3], "mean_batch_fill": totals[0] / max(steps * n_gpus, 1) / args.batch,
+            "eval_cache_hits": totals[4], "ladder_readouts": totals[5], "ladder_budget_hits": totals[6],
+            "seconds_timed": dt, "wall_s_incl_setup_and_warmup": wall,
             "conv3x3_mfma_frac_end_to_end": pps * conv3_flops / 1e12 / (PEAK_FP16_MFMA_TFLOPS * n_gpus),
-            "roofline": roof, "cpu_baseline": cpu, "selfplay": selfplay,
+            "engine_only": {"value": eng_pps, "unit": "positions/s", "steps": args.engine_steps,
+                            "ms_per_step": dt_e / args.engine_steps * 1e3,
+                            "what": "forward pass over a resident batch: no host, no PCIe",
+                            "full_net_tflops": eng_pps * total_flops / 1e12,
+                            "conv3x3_mfma_frac": eng_pps * conv3_flops / 1e12 / (PEAK_FP16_MFMA_TFLOPS * n_gpus)},
+            "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    eng.close()
     sharding.finish(shard)
 
 

@@ -572,6 +572,7 @@ int g_rec_gen = 0, g_rec_flush_interval = 128;   // --flush_interval, selfplay/m
 bool g_init_state_sampling = true;
 float g_use_seen_state_prob = 0.5f, g_sel_mult_base = 0.0f, g_sel_mult_scale = 1.0f;
 int g_num_groups = 2;
+long g_step_limit = 0;   // > 0: the measured region ends after this many engine batches
 long g_last_reuse_added = 0, g_last_examples = 0;
 }
 
@@ -591,6 +592,10 @@ void p3host_selfplay_set_policy(int init_state_sampling, float use_seen_state_pr
 // engine instance and is either being advanced on the host or evaluated on the GPU; with G
 // groups up to G - 1 forward passes are in flight while one group is on the host.
 void p3host_selfplay_set_groups(int n) { g_num_groups = n < 2 ? 2 : (n > 8 ? 8 : n); }
+// > 0: subsequent p3host_selfplay_run calls measure exactly ceil(batches / groups) rounds of one
+// engine batch per group (bench.py's --steps) instead of running for `seconds`; 0 restores the
+// time limit.
+void p3host_selfplay_set_step_limit(long batches) { g_step_limit = batches > 0 ? batches : 0; }
 // reuse-buffer insertions and training examples written by the last p3host_selfplay_run
 long p3host_selfplay_last_reuse_added() { return g_last_reuse_added; }
 long p3host_selfplay_last_examples() { return g_last_examples; }
@@ -745,7 +750,8 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   long base_runs = 0;
   std::chrono::steady_clock::time_point t_start;
   bool measuring = false;
-  long iter = 0;
+  long iter = 0, measured_rounds = 0;
+  const long round_limit = g_step_limit > 0 ? (g_step_limit + NG - 1) / NG : 0;
   for (;;) {
     for (int h = 0; h < NG && rc == 0; ++h) {
       if (!wait_run(h)) {
@@ -768,7 +774,12 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
       t_start = std::chrono::steady_clock::now();
       measuring = true;
     }
-    if (measuring && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= seconds) break;
+    else if (measuring) ++measured_rounds;
+    if (measuring && round_limit > 0) {
+      if (measured_rounds >= round_limit) break;
+    } else if (measuring && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= seconds) {
+      break;
+    }
   }
   for (int h = 0; h < NG; ++h) wait_run(h);
   double secs = measuring ? std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() : 0;

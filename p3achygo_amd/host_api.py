@@ -207,6 +207,14 @@ def set_groups(n: int) -> None:
     L.p3host_selfplay_set_groups(n)
 
 
+def set_step_limit(batches: int) -> None:
+    """> 0: subsequent selfplay_run calls time exactly ceil(batches / groups) rounds of one engine
+    batch per game group (bench.py --steps) instead of running for `seconds`; 0 = time limit."""
+    L = lib()
+    L.p3host_selfplay_set_step_limit.argtypes = [C.c_long]
+    L.p3host_selfplay_set_step_limit(int(batches))
+
+
 def last_run_counters():
     """(reuse-buffer insertions, training examples written) of the last selfplay_run."""
     L = lib()

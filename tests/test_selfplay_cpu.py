@@ -333,3 +333,28 @@ def test_move_sel_manager_known_answers(host):
     assert o[0] == pytest.approx(1.15, rel=1e-3)
     o = sel(20, 0.1, 0.00005, 5.0, 0.0)                  # floor 0.3 and bonus cap: 1 + 0.6*(5-0.1463)/(0.65-0.1463) capped 2.5
     assert o[4] == pytest.approx(0.3) and o[1] == pytest.approx(2.5) and o[0] == pytest.approx(0.75)
+
+
+def test_selfplay_host_over_the_cpu_engine_and_step_limit(built, weight_files):
+    """The CPU baseline leg of bench.py: the same self-play host binds the CPU fp32 oracle through
+    the same C ABI (oracle/libp3cpu_engine.so, loaded with dlopen exactly like libp3hip.so), and
+    with a step limit the timed region is exactly `steps` engine batches: `steps` batches' worth of
+    leaf positions are loaded in it (+ the one batch per group in flight when it ends)."""
+    import os
+    from conftest import ROOT
+    from p3achygo_amd import host_api
+    lib = os.path.join(ROOT, "oracle", "libp3cpu_engine.so")
+    assert os.path.exists(lib)
+    os.environ["P3CPU_THREADS"] = "4"
+    host_api.set_groups(2)
+    host_api.set_step_limit(6)
+    try:
+        st = host_api.selfplay_run(weight_files("test_b3c128btl2"), num_games=16, num_threads=2, seconds=0.0,
+                                   default_n=8, default_k=4, selected_n=8, selected_k=4, max_moves=40,
+                                   warmup_batches=1, seed=3, engine_lib=lib)
+    finally:
+        host_api.set_step_limit(0)
+    assert st.batches == 6 + 2                       # 3 rounds x 2 groups, + the drain of the last round
+    assert 0 < st.positions <= 6 * 8                 # at most one full batch of 8 games per step
+    assert st.positions >= 6 * 8 - 16                # terminal / cached leaves leave a few slots empty
+    assert st.seconds > 0

@@ -323,6 +323,105 @@ __device__ __forceinline__ void residual_add16(f32x4 (&acc)[4][NTn], const ResRe
     }
 }
 
+// Reduce input of a block from x fetched in the accumulator-quad layout (residual_load16 of
+// channel half `cofs`): A = mish(bn0(x)) as packed fp16, ready for epilogue_write16.
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void activate_loaded16(EpiOut16<NTn>& A, const ResRegs16<NTn>& xin,
+                                                  const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, int cofs) {
+  const int q = launder(threadIdx.x & 63) >> 4;
+  const int c0 = cofs + cg_of<G, COUT_PASS>() * 64 + q * 4;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const f32x4 sc = *(const f32x4*)(scale + c0 + 16 * ct), sh = *(const f32x4*)(shift + c0 + 16 * ct);
+#pragma unroll
+    for (int b = 0; b < NTn / 2; ++b) {
+      h4 r0, r1;
+      residual_unpack16<NTn>(xin, b, ct, r0, r1);
+      A.o[2 * b][ct] = bn_mish4(f32x4{(float)r0[0], (float)r0[1], (float)r0[2], (float)r0[3]}, sc, sh);
+      A.o[2 * b + 1][ct] = bn_mish4(f32x4{(float)r1[0], (float)r1[1], (float)r1[2], (float)r1[3]}, sc, sh);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // one cout tile at a time: bounds the live temporaries
+  }
+}
+
+// The same in two steps for a half that must wait in registers across a K loop: stash16 parks
+// the fetched pieces in A's registers as they are (a renaming: A and the pieces are never live
+// together, so the block kernel carries ONE 48-register value across its first K slice whether
+// it came from HBM or from the previous block's expand), activate_stashed16 turns them into A.
+template <int NTn>
+__device__ __forceinline__ void stash16(EpiOut16<NTn>& A, const ResRegs16<NTn>& xin) {
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int b = 0; b < NTn / 2; ++b) {
+      const h8 v = xin.rv[b][ct];
+      A.o[2 * b][ct] = h4{v[0], v[1], v[2], v[3]};
+      A.o[2 * b + 1][ct] = h4{v[4], v[5], v[6], v[7]};
+    }
+}
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void activate_stashed16(EpiOut16<NTn>& A, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, int cofs) {
+  const int q = launder(threadIdx.x & 63) >> 4;
+  const int c0 = cofs + cg_of<G, COUT_PASS>() * 64 + q * 4;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const f32x4 sc = *(const f32x4*)(scale + c0 + 16 * ct), sh = *(const f32x4*)(shift + c0 + 16 * ct);
+#pragma unroll
+    for (int b = 0; b < NTn / 2; ++b) {
+      h4 r0 = A.o[2 * b][ct], r1 = A.o[2 * b + 1][ct];
+      half_swap(r0, r1);
+      A.o[2 * b][ct] = bn_mish4(f32x4{(float)r0[0], (float)r0[1], (float)r0[2], (float)r0[3]}, sc, sh);
+      A.o[2 * b + 1][ct] = bn_mish4(f32x4{(float)r1[0], (float)r1[1], (float)r1[2], (float)r1[3]}, sc, sh);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Expand epilogue of the position-major block kernel: x' = acc + residual -> fp16 -> HBM, and,
+// when `act`, A = mish(bn0_next(x')) of the same fp16 values for the next block's reduce (cofs =
+// channel half of this pass; scale/shift = the next block's folded bn0).
+template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void epilogue_store16_act(f32x4 (&acc)[4][NTn], const ResRegs16<NTn>& rr,
+                                                     _Float16* __restrict__ x, EpiOut16<NTn>& A, bool act,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int cofs) {
+  const int q = launder(threadIdx.x & 63) >> 4;
+  const int c0 = cofs + cg_of<G, COUT_PASS>() * 64 + q * 4;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    char* xc = (char*)x + (size_t)ct * (2 * kNLoc * 8 * 2);
+    f32x4 sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0};
+    if (act) {
+      sc = *(const f32x4*)(scale + c0 + 16 * ct);
+      sh = *(const f32x4*)(shift + c0 + 16 * ct);
+    }
+#pragma unroll
+    for (int b = 0; b < NTn / 2; ++b) {
+      h4 r0, r1;
+      residual_unpack16<NTn>(rr, b, ct, r0, r1);
+      h4 o0, o1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o0[i] = (_Float16)(acc[ct][2 * b][i] + (float)r0[i]);
+        o1[i] = (_Float16)(acc[ct][2 * b + 1][i] + (float)r1[i]);
+      }
+      if (act) {
+        A.o[2 * b][ct] = bn_mish4(f32x4{(float)o0[0], (float)o0[1], (float)o0[2], (float)o0[3]}, sc, sh);
+        A.o[2 * b + 1][ct] = bn_mish4(f32x4{(float)o1[0], (float)o1[1], (float)o1[2], (float)o1[3]}, sc, sh);
+      } else {   // defined on every path, or the previous block's A stays live through this one
+        A.o[2 * b][ct] = h4{0, 0, 0, 0};
+        A.o[2 * b + 1][ct] = h4{0, 0, 0, 0};
+      }
+      half_swap(o0, o1);   // every lane takes part: partners of invalid rows may be valid
+      const h8 piece = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+      if (rr.ok[b]) *(h8*)(xc + (uint32_t)(rr.base[b] * 2u)) = piece;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <bool RESIDUAL, int NTn>
 __device__ __forceinline__ void epilogue_store16(f32x4 (&acc)[4][NTn], const ResRegs16<NTn>& rr,
                                                  _Float16* __restrict__ x) {

@@ -272,8 +272,20 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
     e->game_b_off = ar.add(wf.get("init_game.b", (size_t)C).data, C * 4);
   }
   bool have_xa = false;   // layer-wise path: u holds mish(bn0(x)) of the next block
+  // The weight streams of consecutive fused blocks go into the arena back to back, after the
+  // run's other tensors: one k_block launch walks the streams of all its blocks as ONE circular
+  // stream (position-major order, kernels.hip), so a run must be contiguous.
+  std::vector<std::pair<size_t, std::vector<_Float16>>> run_streams;   // (block index, stream)
+  auto flush_run = [&]() {
+    for (auto& rs : run_streams) {
+      BlockPlan& b = e->blocks[rs.first];
+      b.stream_off = add_stream(ar, rs.second, b.nms, Cb);
+    }
+    run_streams.clear();
+  };
   for (int i = 0; i < wf.nblocks; ++i) {
     BlockPlan bp;
+    if (wf.is_broadcast(i) || layerwise) flush_run();
     const std::string p = "blocks." + std::to_string(i);
     // conv j of this block, checked against the [k][k][cin][cout] size the packer will read
     auto W = [&](int j, int kw, int cin, int cout) {
@@ -357,10 +369,11 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
       for (int ip = 0; ip < C / CB; ++ip) pack_segment(s, W(0, 1, C, Cb), 1, 1, C, Cb, ip * CB, CB, 0, CB);
       for (int j = 1; j < nconv - 1; ++j) pack_segment(s, W(j, 3, Cb, Cb), 9, 9, Cb, Cb, 0, CB, 0, CB);
       for (int cp = 0; cp < C / CB; ++cp) pack_segment(s, W(nconv - 1, 1, Cb, C), 1, 1, Cb, C, 0, CB, cp * CB, CB);
-      bp.stream_off = add_stream(ar, s, bp.nms, CB);
+      run_streams.emplace_back(e->blocks.size(), std::move(s));
     }
     e->blocks.push_back(bp);
   }
+  flush_run();
   // heads: conv_p | conv_g | value.conv  -> [C][96]
   {
     std::vector<float> w((size_t)C * 96);
@@ -417,10 +430,11 @@ p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
   a.t = e->d_t;
   a.npos = npos;
   a.nblk = count;
+  // the streams of consecutive fused blocks lie back to back in the arena (build_plan)
+  a.wstream = e->d_arena + e->blocks[first].stream_off;
   for (int b = 0; b < count; ++b) {
     const BlockPlan& bp = e->blocks[first + b];
-    a.blk[b].wstream = e->d_arena + bp.stream_off;
-    a.blk[b].nms_total = bp.nms;
+    a.nms_total += bp.nms;
     for (int j = 0; j < p3::kMaxBlockLayers; ++j) {
       a.blk[b].scale[j] = e->dev<float>(bp.bn[j].scale_off);
       a.blk[b].shift[j] = e->dev<float>(bp.bn[j].shift_off);

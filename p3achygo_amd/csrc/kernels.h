@@ -29,8 +29,6 @@ constexpr int kMaxBlockLayers = 8;
 // grid-wide dependency, just the launch boundaries (ramp, tail, cold ring) saved.
 constexpr int kMaxFuse = 6;
 struct BlockParams {
-  const void* wstream;  // packed weight stream of the block
-  int nms_total;        // its length in macro-steps
   const float* scale[kMaxBlockLayers];  // folded BN of conv j's prologue
   const float* shift[kMaxBlockLayers];
 };
@@ -39,6 +37,8 @@ struct BlockArgs {
   _Float16* t;          // nbt: scratch for the inner residual stream [pos][CB/8][361][8]
   int npos;
   int nblk;
+  const void* wstream;  // the packed weight streams of the launch's blocks, back to back
+  int nms_total;        // their total length in macro-steps (the ring walks them circularly)
   BlockParams blk[kMaxFuse];
 };
 

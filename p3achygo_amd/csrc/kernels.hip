@@ -25,6 +25,20 @@ namespace p3 {
 //   reduce: for each CB-slice of C input channels; inner 3x3 convs in order; expand: for
 //   each CB-slice of C output channels.
 // =======================================================================================
+// Loop order: POSITION major.  A workgroup takes a position (two at C = 128) through every block
+// of the launch before it moves on, so between two blocks of a launch the residual stream never
+// comes back from HBM as a conv operand: the expand epilogue already holds x' = x + conv(..) in
+// the accumulator-quad layout the act buffer is written in (4 consecutive channels of one board
+// point per lane), applies the NEXT block's bn0 + mish right there and keeps the two activated
+// 128-channel halves as packed fp16 (A0, A1) until the act buffer is free.  x' still goes to HBM
+// once per block — it is the next block's residual (read back by the lane that stored it, an L2
+// hit) and the launch's output.  The first block of a position takes the same path with A0/A1
+// made from x fetched in that same layout.  The blocks' weight streams are packed back to back
+// (engine.cpp), so the ring walks one circular stream per launch and never drains.
+//
+// The values are the ones the block-major order produced: bn0 + mish is applied to the fp16
+// value that is stored, exactly what a re-load would return (bit-identical to one launch per
+// block, tests/test_engine_gpu.py::test_fused_block_launches_equal_one_launch_per_block).
 template <int C, int CB, int KIND, int L>
 __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
   constexpr int NPOS = 128 / CB;
@@ -33,107 +47,108 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
   constexpr int NT = T::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr uint32_t kRingOff = G::ACT_BYTES;
+  static_assert(C / CB == 2, "two input slices / two output passes");
 
   act_zero<G>(smem);
   Ring<T::RS> ring;
-  ring_init(ring, smem, a.blk[0].wstream, a.blk[0].nms_total, kRingOff);
+  ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
   lds_barrier();
 
-  static_assert(C / CB == 2, "two input slices / two output passes");
-#pragma unroll 1
-  for (int blk = 0; blk < a.nblk; ++blk) {
-  const BlockParams& bp = a.blk[blk];
-  if (blk > 0) {
-    // Block boundary: this workgroup's own stores of the previous block (other waves wrote
-    // the pieces this wave stages) must have been acknowledged before they are read back.
-    ring_drain();
-    __builtin_amdgcn_s_barrier();
-    ring.gend = ring.gbeg + (size_t)bp.nms_total * T::RS;   // gbeg was switched during the last position
-  }
-  XRegs<G> xr;
-  stage_load<G>(xr, a.x, C, blockIdx.x * NPOS, a.npos, 0);
-  stage_math<G>(xr, 0, bp.scale[0], bp.shift[0]);
   int npos_done = 0;
   for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS, ++npos_done) {
-    f32x4 acc[4][NT];
-    const int pos_next = pos0 + gridDim.x * NPOS;
-    // last position of a block that is not the last: the weight prefetch wraps into the next
-    // block's stream instead of this block's start
-    if (pos_next >= a.npos && blk + 1 < a.nblk) ring_retarget(ring, a.blk[blk + 1].wstream);
-    // ---- reduce 1x1 (C -> CB), prologue bn0+mish applied to the fetched slice in
-    // registers; slice 1 is fetched under the slice-0 MFMAs -------------------------------
-    stage_store<G, false>(smem, xr, 0, nullptr, nullptr);
-    acc16_zero<NT>(acc);
-    stage_load<G>(xr, a.x, C, pos0, a.npos, G::NCH);
-    // younger than the glds the next two acquires wait for: these 12 loads and, after the
-    // first position, the 12 output stores of the previous position's last pass (the 12
-    // loads of the next-position prefetch issued before them are already consumed)
-    ring_note_inflight(ring, npos_done == 0 ? 12 : 24);
-    conv_segment16<G, CB, 1, 1>(ring, smem, acc);
-    stage_math<G>(xr, G::NCH, bp.scale[0], bp.shift[0]);
-    lds_barrier();
-    stage_store<G, false>(smem, xr, G::NCH, nullptr, nullptr);
-    conv_segment16<G, CB, 1, 1>(ring, smem, acc);
-    if (KIND == 0) {
+    EpiOut16<NT> A1;   // activated reduce input, channel half 1, made by the previous block's expand
+#pragma unroll 1
+    for (int blk = 0; blk < a.nblk; ++blk) {
+      const BlockParams& bp = a.blk[blk];
+      const bool from_hbm = blk == 0;
+      const bool last = blk + 1 == a.nblk;
+      f32x4 acc[4][NT];
+      // ---- reduce 1x1 (C -> CB): the act buffer is free here (barrier at the end of the
+      // previous block / position), half 0 goes in, half 1 follows under the barrier after the
+      // first K slice ------------------------------------------------------------------------
+      // x of a position's first block arrives in the accumulator-quad layout (12 sixteen-byte
+      // loads per half), half 1 under the first K slice
+      if (from_hbm) {
+        ResRegs16<NT> xin;
+        EpiOut16<NT> A0;
+        residual_addr16<G, CB, NT>(xin, C, pos0, a.npos, 0);
+        residual_load16<NT>(xin, a.x);
+        activate_loaded16<G, CB, NT>(A0, xin, bp.scale[0], bp.shift[0], 0);
+        residual_addr16<G, CB, NT>(xin, C, pos0, a.npos, CB);
+        residual_load16<NT>(xin, a.x);
+        stash16<NT>(A1, xin);   // half 1 waits in A1's registers, still raw
+        epilogue_write16<G, CB, NT>(smem, A0, 0);
+      }   // otherwise half 0 was written at the end of the previous block
+      // ordinary vector-memory operations issued since the ring's last prefetch, all younger than
+      // the glds the next two acquires wait for: the 12 residual loads and 12 stores of the
+      // previous block's last pass (any block but the launch's very first), and the two halves
+      // of x (24 loads) in a position's first block
+      ring_note_inflight(ring, from_hbm ? (npos_done == 0 ? 24 : 48) : 24);
+      acc16_zero<NT>(acc);
+      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      if (from_hbm) activate_stashed16<G, CB, NT>(A1, bp.scale[0], bp.shift[0], CB);
+      lds_barrier();
+      epilogue_write16<G, CB, NT>(smem, A1, 0);
+      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      if (KIND == 0) {
 #pragma unroll
-      for (int j = 1; j <= L; ++j) {
-        epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[j], bp.shift[j]);
-        acc16_zero<NT>(acc);
-        conv_segment16<G, CB, 3, 9>(ring, smem, acc);
-      }
-      epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[L + 1], bp.shift[L + 1]);
-    } else {
-      // nbt: the raw inner residual stream t is parked in HBM scratch (fp16, as the reference's
-      // fp16 engine keeps it) instead of 96 fp32 registers per lane: it is written once after
-      // the reduce conv, read back after the second conv of each pair, and t' = t + conv(...) is
-      // written back once.
-      ResRegs16<NT> tr;
-      residual_addr16<G, CB, NT>(tr, CB, pos0, a.npos, 0);
-      epilogue_store16<false, NT>(acc, tr, a.t);
-      epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[1], bp.shift[1]);
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        acc16_zero<NT>(acc);
-        conv_segment16<G, CB, 3, 9>(ring, smem, acc);
-        epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[2 + 2 * r], bp.shift[2 + 2 * r]);
-        acc16_zero<NT>(acc);
-        conv_segment16<G, CB, 3, 9>(ring, smem, acc);
-        // t is fetched after the K loop: holding it across the 3x3 loop costs more (spills of
-        // the loaded values, i.e. the same exposed latency plus scratch traffic)
+        for (int j = 1; j <= L; ++j) {
+          epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[j], bp.shift[j]);
+          acc16_zero<NT>(acc);
+          conv_segment16<G, CB, 3, 9>(ring, smem, acc);
+        }
+        epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[L + 1], bp.shift[L + 1]);
+      } else {
+        // nbt: the raw inner residual stream t is parked in HBM scratch (fp16, as the reference's
+        // fp16 engine keeps it) instead of 96 fp32 registers per lane: it is written once after
+        // the reduce conv, read back after the second conv of each pair, and t' = t + conv(...) is
+        // written back once.
+        ResRegs16<NT> tr;
         residual_addr16<G, CB, NT>(tr, CB, pos0, a.npos, 0);
-        residual_load16<NT>(tr, a.t);
-        residual_add16<NT>(acc, tr);
-        if (r == 0) epilogue_store16<false, NT>(acc, tr, a.t);
-        epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[3 + 2 * r], bp.shift[3 + 2 * r]);
+        epilogue_store16<false, NT>(acc, tr, a.t);
+        epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[1], bp.shift[1]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          acc16_zero<NT>(acc);
+          conv_segment16<G, CB, 3, 9>(ring, smem, acc);
+          epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[2 + 2 * r], bp.shift[2 + 2 * r]);
+          acc16_zero<NT>(acc);
+          conv_segment16<G, CB, 3, 9>(ring, smem, acc);
+          // t is fetched after the K loop: holding it across the 3x3 loop costs more (spills of
+          // the loaded values, i.e. the same exposed latency plus scratch traffic)
+          residual_addr16<G, CB, NT>(tr, CB, pos0, a.npos, 0);
+          residual_load16<NT>(tr, a.t);
+          residual_add16<NT>(acc, tr);
+          if (r == 0) epilogue_store16<false, NT>(acc, tr, a.t);
+          epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[3 + 2 * r], bp.shift[3 + 2 * r]);
+        }
+      }
+      // ---- expand 1x1 (CB -> C) + residual -> HBM, and (unless this is the launch's last
+      // block) the next block's activated reduce input.  Pass 0's residual is requested before
+      // its K loop; pass 1's only after its K loop — A0 occupies those registers meanwhile —
+      // and lands under the barrier that follows -------------------------------------------------
+      const float* nsc = last ? bp.scale[0] : a.blk[blk + 1].scale[0];
+      const float* nsh = last ? bp.shift[0] : a.blk[blk + 1].shift[0];
+      {
+        ResRegs16<NT> rr;
+        EpiOut16<NT> A0;
+        residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, 0);
+        residual_load16<NT>(rr, a.x);
+        ring_note_inflight(ring, 12);
+        acc16_zero<NT>(acc);
+        conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+        epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A0, !last, nsc, nsh, 0);
+        ring_note_inflight(ring, 12);   // pass 0's stores
+        acc16_zero<NT>(acc);
+        conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+        residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, CB);
+        residual_load16<NT>(rr, a.x);
+        lds_barrier();   // every wave is done with the act buffer
+        if (!last) epilogue_write16<G, CB, NT>(smem, A0, 0);   // the next block's reduce input, half 0
+        epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, !last, nsc, nsh, CB);
       }
     }
-    // ---- expand 1x1 (CB -> C) + residual, straight to HBM.  The residual of each output
-    // pass is loaded before that pass's MFMAs (12 sixteen-byte loads/lane); in pass 1 the 12
-    // stores of pass 0 are in flight as well ------------------------------------------------------
-    {
-      // Pass 1's residual is requested before pass 0's output stores go out: vmcnt retires in
-      // issue order, so loads issued behind the stores would also wait for the stores' acks.
-      ResRegs16<NT> rr0, rr1;
-      residual_addr16<G, CB, NT>(rr0, C, pos0, a.npos, 0);
-      residual_load16<NT>(rr0, a.x);
-      ring_note_inflight(ring, 12);
-      acc16_zero<NT>(acc);
-      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
-      residual_addr16<G, CB, NT>(rr1, C, pos0, a.npos, CB);
-      residual_load16<NT>(rr1, a.x);
-      epilogue_store16<true, NT>(acc, rr0, a.x);
-      ring_note_inflight(ring, 24);
-      acc16_zero<NT>(acc);
-      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
-      // next position's first slice: issued once the last K loop of this position is over
-      // (no fragment registers live), lands under the residual epilogue's stores
-      stage_load<G>(xr, a.x, C, pos_next, a.npos, 0);
-      epilogue_store16<true, NT>(acc, rr1, a.x);
-    }
-    stage_math<G>(xr, 0, bp.scale[0], bp.shift[0]);   // next position's slice 0, before the barrier
-    lds_barrier();
   }
-  }   // blocks
   ring_drain();
 }
 

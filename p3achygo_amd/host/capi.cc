@@ -88,6 +88,76 @@ void p3host_unapply_symmetry(int sym, p3hip_result* r) { UnapplySymmetry((Symmet
 
 extern "C" void p3host_softmax(const float* in, float* out, int n) { SoftmaxN(in, out, n); }
 
+// ---- bias cache (bias_cache.h) ------------------------------------------------------------------
+extern "C" {
+// LocalPattern::FromCurrentPosition of a game handle: returns 0 when the position has no pattern
+// (no stone as last move, or no move two plies back); otherwise fills the three 5x5 maps (grid:
+// 1 black, -1 white, 2 off board) and sets same[0..2] to whether the grid / atari / ko hashes
+// equal those of the game `other` (may be null).
+int p3host_test_local_pattern(void* game, void* other, int8_t* grid, int8_t* atari, int8_t* ko, int* same) {
+  const auto p = LocalPattern::FromCurrentPosition(Position(*(Game*)game));
+  if (!p) return 0;
+  std::memcpy(grid, p->grid.data(), 25);
+  std::memcpy(atari, p->atari.data(), 25);
+  std::memcpy(ko, p->ko.data(), 25);
+  if (other && same) {
+    const auto q = LocalPattern::FromCurrentPosition(Position(*(Game*)other));
+    same[0] = q && q->grid_hash == p->grid_hash;
+    same[1] = q && q->atari_hash == p->atari_hash;
+    same[2] = q && q->ko_hash == p->ko_hash;
+    same[3] = q && q->last_move.loc == p->last_move.loc && q->last_move.color == p->last_move.color &&
+              q->two_moves_ago.loc == p->two_moves_ago.loc;
+  }
+  return 1;
+}
+// Scripted BiasCache arithmetic on two nodes that share one entry.  Node k (k = 0, 1) has own
+// estimate init[k], n[k] visits and three children with visits cv[k][0..2] and values cvv[k][0..2].
+// Steps: update node 0, update node 1, give node 0's first child `extra` more visits and update it
+// again, release node 1 (its destructor), read-only fetch through node 0.  out[0..4] = the five
+// returned biases; out[5], out[6] = the entry (error, weight) at the end; out[7] = node 0's v after
+// RecomputeNodeStats with the last bias; out[8] = entries left after node 0 is released and the
+// cache pruned.
+void p3host_test_bias_cache_math(float alpha, float lambda, const float* init, const int* cv, const float* cvv,
+                                 int extra, float* out) {
+  BiasCache cache(alpha, lambda);
+  NodePool pool;
+  TreeNode* nodes[2] = {pool.Create(), pool.Create()};
+  Game g(7.5f, true);
+  g.PlayMove(Loc{3, 3}, kBlack);
+  g.PlayMove(Loc{15, 15}, kWhite);
+  const Position pos(g);
+  for (int k = 0; k < 2; ++k) {
+    TreeNode* nd = nodes[k];
+    nd->evaluated = true;
+    nd->init_util_est = init[k];
+    nd->n = 1;
+    for (int c = 0; c < 3; ++c) {
+      TreeNode* ch = pool.Create();
+      ch->v = cvv[k * 3 + c];
+      ch->n = cv[k * 3 + c];
+      nd->children.push_back(ChildEdge{(int16_t)c, cv[k * 3 + c], ch});
+      nd->n += cv[k * 3 + c];
+    }
+    AssignBiasCacheEntry(&cache, pos, nd);   // same position: both get the same entry
+  }
+  out[0] = UpdateAndFetchObsBias(&cache, nodes[0]);
+  out[1] = UpdateAndFetchObsBias(&cache, nodes[1]);
+  nodes[0]->children[0].visits += extra;
+  nodes[0]->n += extra;
+  out[2] = UpdateAndFetchObsBias(&cache, nodes[0]);
+  RecomputeNodeStats(nodes[0], out[2]);
+  out[7] = nodes[0]->v;
+  nodes[1]->bias.Release();
+  out[3] = cache.Fetch(nodes[0]->bias);
+  out[4] = cache.Fetch(nodes[1]->bias);   // no entry any more: 0
+  out[5] = nodes[0]->bias.bias_cache_entry->err;
+  out[6] = nodes[0]->bias.bias_cache_entry->weight;
+  nodes[0]->bias.Release();
+  cache.PruneUnused();
+  out[8] = (float)cache.size();
+}
+}
+
 // k > 0: Gumbel root search (n, k); k == 0: SearchRootPuct with n playouts (self-play's
 // fast-move parameters).
 extern "C" int p3host_test_scripted_search(int n, int k, int* child_visits, float* child_q, int* nn_move,

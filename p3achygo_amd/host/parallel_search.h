@@ -96,39 +96,6 @@ inline TopActions PuctTopScores(const TreeNode* node, const Board& board, Color 
   return top;
 }
 
-// tree.h:175-241 (no bias cache: obs_bias = 0)
-inline void RecomputeNodeStats(TreeNode* node) {
-  float w = node->init_util_est, w_outcome = node->init_outcome_est, total_score = node->init_score_est,
-        w_err = node->init_err_est;
-  int max_child_n = 0;
-  for (const ChildEdge& e : node->children) {
-    if (!e.node) continue;
-    w -= e.visits * e.node->v;
-    w_outcome -= e.visits * e.node->v_outcome;
-    total_score -= e.visits * e.node->score;
-    max_child_n = std::max(max_child_n, e.visits);
-    w_err += e.visits * e.node->v_err;
-  }
-  const float v = w / node->n, v_outcome = w_outcome / node->n;
-  const float m = node->init_util_est - v, m_outcome = node->init_outcome_est - v_outcome;
-  float m2 = m * m, m2_outcome = m_outcome * m_outcome;
-  double m3 = m2 * m, m3_outcome = m2_outcome * m_outcome;
-  for (const ChildEdge& e : node->children) {
-    if (e.visits == 0 || !e.node) continue;
-    const float dv = -e.node->v - v, dvo = -e.node->v_outcome - v_outcome;
-    m2 += e.visits * (e.node->v_var + dv * dv);
-    m2_outcome += e.visits * (e.node->v_outcome_var + dvo * dvo);
-    m3 += e.visits * (-e.node->v_m3 + 3 * e.node->v_var * dv + dv * dv * dv);
-    m3_outcome += e.visits * (-e.node->v_outcome_m3 + 3 * e.node->v_outcome_var * dvo + dvo * dvo * dvo);
-  }
-  node->w = w; node->w_outcome = w_outcome; node->v = v; node->v_outcome = v_outcome;
-  node->score = total_score / node->n;
-  node->max_child_n = max_child_n;
-  node->v_var = m2 / node->n; node->v_outcome_var = m2_outcome / node->n;
-  node->v_m3 = m3 / node->n; node->v_outcome_m3 = m3_outcome / node->n;
-  node->v_err = w_err / node->n;
-}
-
 enum class SearchMode : uint8_t { kConcurrent = 0, kBatch = 1 };                           // Search::Mode
 enum class CollisionPolicy : uint8_t { kAbort = 0, kRetry = 1, kSmartRetry = 2 };          // search.h:28-32
 enum class CollisionDetector : uint8_t { kNoOp = 0, kNInFlight = 1, kLevelSaturation = 2, kProduct = 3 };   // :34-39

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/p3hip.h"
+#include "bias_cache.h"
 #include "board.h"
 #include "rng.h"
 
@@ -61,6 +62,7 @@ struct TreeNode {                                        // cc/mcts/tree.h:21-91
   float init_outcome_est = 0, init_score_est = 0, init_score_var = 0, init_util_est = 0, init_err_est = 0;
   uint32_t mark = 0;  // NodePool::Reap
   int n_in_flight = 0;  // descents of the current round through this node (parallel_search.h)
+  BiasNodeState bias;   // bias_cache_entry / last_obs_bias_term / last_weight_term, tree.h:83-86
 
   ChildEdge* edge(int a) {
     for (auto& e : children)
@@ -112,13 +114,14 @@ class NodePool {
     size_t keep = 0;
     for (TreeNode* n : live_) {
       if (n->mark == epoch_) live_[keep++] = n;
-      else { free_.push_back(n); ++reaped; }
+      else { n->bias.Release(); free_.push_back(n); ++reaped; }   // ~TreeNode, tree.h:23-32
     }
     live_.resize(keep);
     return reaped;
   }
   void Clear() { Reap(nullptr); }
   size_t Size() const { return live_.size(); }
+  ~NodePool() { for (TreeNode* n : live_) n->bias.Release(); }
 
  private:
   std::vector<std::unique_ptr<TreeNode>> owned_;
@@ -188,6 +191,60 @@ inline void EvaluateTerminal(const Scores& s, TreeNode* node, Color c, Color roo
   node->init_util_est = (ps > os ? 1.0f : -1.0f) + su;
   node->init_outcome_est = ps > os ? 1.0f : -1.0f;
   node->init_score_est = final_score;
+}
+
+// ---- idempotent node statistics (tree.h:175-241) and the bias-cache hooks ---------------------
+// Recomputes every statistic of `node` from its own estimate (less `obs_bias`) and its
+// children's current statistics: used by the graph / parallel searches and, whenever a bias
+// cache is active, by the serial search (gumbel.cc:446-448,608-610).
+inline void RecomputeNodeStats(TreeNode* node, float obs_bias = 0.0f) {
+  const float adj_init_util_est = node->init_util_est - obs_bias;
+  float w = adj_init_util_est, w_outcome = node->init_outcome_est, total_score = node->init_score_est,
+        w_err = node->init_err_est;
+  int max_child_n = 0;
+  for (const ChildEdge& e : node->children) {
+    if (!e.node) continue;
+    w -= e.visits * e.node->v;
+    w_outcome -= e.visits * e.node->v_outcome;
+    total_score -= e.visits * e.node->score;
+    max_child_n = std::max(max_child_n, e.visits);
+    w_err += e.visits * e.node->v_err;
+  }
+  const float v = w / node->n, v_outcome = w_outcome / node->n;
+  const float m = adj_init_util_est - v, m_outcome = node->init_outcome_est - v_outcome;
+  float m2 = m * m, m2_outcome = m_outcome * m_outcome;
+  double m3 = m2 * m, m3_outcome = m2_outcome * m_outcome;
+  for (const ChildEdge& e : node->children) {
+    if (e.visits == 0 || !e.node) continue;
+    const float dv = -e.node->v - v, dvo = -e.node->v_outcome - v_outcome;
+    m2 += e.visits * (e.node->v_var + dv * dv);
+    m2_outcome += e.visits * (e.node->v_outcome_var + dvo * dvo);
+    m3 += e.visits * (-e.node->v_m3 + 3 * e.node->v_var * dv + dv * dv * dv);
+    m3_outcome += e.visits * (-e.node->v_outcome_m3 + 3 * e.node->v_outcome_var * dvo + dvo * dvo * dvo);
+  }
+  node->w = w; node->w_outcome = w_outcome; node->v = v; node->v_outcome = v_outcome;
+  node->score = total_score / node->n;
+  node->max_child_n = max_child_n;
+  node->v_var = m2 / node->n; node->v_outcome_var = m2_outcome / node->n;
+  node->v_m3 = m3 / node->n; node->v_outcome_m3 = m3_outcome / node->n;
+  node->v_err = w_err / node->n;
+}
+
+// GumbelEvaluator::AssignBiasCacheEntry, gumbel.cc:729-736 (search.cc:39-46)
+inline void AssignBiasCacheEntry(BiasCache* cache, const Position& pos, TreeNode* node) {
+  if (!cache) return;
+  const std::optional<LocalPattern> pattern = LocalPattern::FromCurrentPosition(pos);
+  if (!pattern) return;
+  node->bias.bias_cache_entry = cache->GetOrCreate(*pattern);
+}
+// BiasCache::UpdateAndFetch(node), bias_cache.h:156-187 (FetchObsBias, search.cc:48-52): 0 without
+// a cache or an entry
+inline float UpdateAndFetchObsBias(BiasCache* cache, TreeNode* node) {
+  if (!cache || !node->bias.bias_cache_entry) return 0.0f;
+  float weighted_child_utility = 0;
+  for (const ChildEdge& e : node->children)
+    if (e.visits > 0) weighted_child_utility += e.visits * -(e.node->v);
+  return cache->UpdateAndFetch(node->bias, node->init_util_est, weighted_child_utility, node->n - 1);
 }
 
 // ---- non-root PUCT (search_policy.h:159-368, IdentityQ / IdentityN) -----------------
@@ -394,6 +451,7 @@ class GumbelSearch {
           return Status::kNeedEval;
         case State::kRootEvalWait:   // Resume() stored the result
           EvaluateRoot(pending_, root_, color_);
+          AssignBiasCacheEntry(bias_cache_, root_pos_, root_);   // gumbel.cc:275-278
           state_ = State::kPrepare;
           break;
         case State::kPrepare:
@@ -425,6 +483,8 @@ class GumbelSearch {
     }
   }
   void Resume(const p3hip_result& r) { pending_ = r; }
+  // GumbelEvaluator's bias_cache constructor argument (gumbel.cc:247-254); nullptr = off
+  void set_bias_cache(BiasCache* cache) { bias_cache_ = cache; }
   const Position* eval_game() const { return eval_game_; }
   Color eval_color() const { return eval_color_; }
   const GumbelResult& result() const { return res_; }
@@ -628,6 +688,7 @@ class GumbelSearch {
       EvaluateTerminal(s, leaf, leaf_color_, color_, root_->init_score_est);
       leaf->evaluated = true;
     }
+    AssignBiasCacheEntry(bias_cache_, search_game_, leaf);   // gumbel.cc:683,724
     Backward();
     ++visits_spent_;
     if (puct_root_) return;   // the root is part of the path and was updated by Backward
@@ -645,7 +706,7 @@ class GumbelSearch {
     }
   }
 
-  static void SingleBackup(TreeNode* node, int a, bool is_leaf, float leaf_q, float leaf_qo, float leaf_score) {
+  void SingleBackup(TreeNode* node, int a, bool is_leaf, float leaf_q, float leaf_qo, float leaf_score) {
     if (is_leaf) {   // gumbel.cc:760-767
       node->n += 1;
       node->w = node->v = node->init_util_est;
@@ -656,6 +717,15 @@ class GumbelSearch {
     node->n += 1;
     ChildEdge* e = node->edge(a);
     e->visits += 1;
+    if (bias_cache_) {
+      // use_idempotent_updates (gumbel.cc:446-448,608-610,770-777): every statistic is recomputed
+      // from the children with the cache's observed bias taken off the node's own estimate; the
+      // value histogram stays incremental as in the reference
+      RecomputeNodeStats(node, UpdateAndFetchObsBias(bias_cache_, node));
+      const int b = std::clamp((int)((leaf_qo + 1.0f) / kBucketRange), 0, kNumVBuckets - 1);
+      node->v_categorical[b] += 1;
+      return;
+    }
     node->w += leaf_q;
     node->w_outcome += leaf_qo;
     node->v = node->w / node->n;
@@ -774,6 +844,7 @@ class GumbelSearch {
   const Position* eval_game_ = nullptr;
   Color eval_color_ = kBlack;
   p3hip_result pending_;
+  BiasCache* bias_cache_ = nullptr;
 };
 
 }  // namespace p3

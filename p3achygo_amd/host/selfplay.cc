@@ -6,8 +6,9 @@
 // otherwise a fast search with per-game k and noise scaling), temperature schedule, Gumbel
 // root search, tree reuse + Reap, pass-alive refresh at moves 200/250/.../400, max_moves,
 // final scoring, init-state sampling (handicap games, GoExploit restarts), the fork manager,
-// down-bad visit annealing, sel_mult and the recorders.  Not restated: the
-// opening book (probability 0 in the reference) and the bias cache (off by default).
+// down-bad visit annealing, sel_mult, the per-game bias cache (--bias_cache_lambda/alpha, on in
+// config/v4.json) and the recorders.  Not restated: the opening book
+// (probability 0 in the reference).
 //
 // Scheduling is new (the reference runs one OS thread per game and a 400 us batching
 // timeout, nn_interface.cc:279-404): games are resumable state machines (search.h) split in
@@ -122,6 +123,7 @@ struct SelfPlayConfig {       // SPConfig, cc/selfplay/self_play_thread.h:38-61
   int default_n = 32, default_k = 5;      // --gumbel_default_{n,k}   selfplay/main.cc:44-47
   int max_moves = 600;                    // --max_moves
   int nonroot_var_scale_prior_visits = 10;
+  float bias_cache_lambda = 0.0f, bias_cache_alpha = 0.8f;   // --bias_cache_{lambda,alpha} main.cc:58-61 (0 = off)
   float use_seen_state_prob = 0.5f;       // --use_seen_state_prob     main.cc:48-50
   float sel_mult_base = 0.0f, sel_mult_scale_factor = 1.0f;   // main.cc:51-57
   ForkParams fork_params = ForkParams::ForReuse(0.5f);        // main.cc:191-193
@@ -146,6 +148,8 @@ constexpr float kPuctFastSearchProb = 0.25f;           // :74
 
 struct GameStats {
   long moves = 0, games = 0, evals = 0, black_wins = 0, cache_hits = 0;
+  long bias_entries_pruned = 0;   // BiasCache::PruneUnused, self_play_thread.cc:730-733
+  double bias_adj_abs_sum = 0;    // sum over moves of |obs_bias| of the root (self_play_thread.cc:639-641)
 };
 
 // Per-game evaluation cache: the reference keeps one LRU per game thread keyed by
@@ -270,6 +274,10 @@ class GameRunner {
     game_.reset(new Game(init.board, init.last_moves, init.move_num));
     color_ = init.color_to_move;
     pool_.Clear();
+    // one bias cache per game (self_play_thread.cc:407-412): the old game's nodes are gone
+    bias_cache_.reset(cfg_.bias_cache_lambda > 0.0f ? new BiasCache(cfg_.bias_cache_alpha, cfg_.bias_cache_lambda)
+                                                    : nullptr);
+    search_.set_bias_cache(bias_cache_.get());
     root_ = pool_.Create();
     move_infos_.clear();
     num_consecutive_down_bad_moves_ = 0;
@@ -387,6 +395,8 @@ class GameRunner {
     const GumbelResult& res = search_.result();
     move_ = res.mcts_move;
     const float root_q_outcome = VOutcome(root_);
+    // bias-cache adjustment of this root, read-only (self_play_thread.cc:638-641; the reference logs it)
+    if (bias_cache_) stats_.bias_adj_abs_sum += std::abs(bias_cache_->Fetch(root_->bias));
     if (cfg_.recorder) {
       MoveSearchRecord mi;
       std::memcpy(mi.mcts_pi, res.pi_improved, sizeof mi.mcts_pi);
@@ -442,6 +452,7 @@ class GameRunner {
     if (!next) next = pool_.Create();
     pool_.Reap(next);   // self_play_thread.cc:711-722
     root_ = next;
+    if (bias_cache_) stats_.bias_entries_pruned += bias_cache_->PruneUnused();   // :730-733
     if (game_->IsGameOver() || game_->num_moves() >= cfg_.max_moves) {
       FinishGame();
       return;
@@ -464,6 +475,7 @@ class GameRunner {
   uint64_t seed_;
   std::unique_ptr<Game> game_;
   Board init_board_;
+  std::unique_ptr<BiasCache> bias_cache_;   // declared before the pool: nodes release their entries first
   NodePool pool_;
   TreeNode* root_ = nullptr;
   Color color_ = kBlack;
@@ -571,6 +583,9 @@ std::string g_rec_dir, g_rec_worker = "0";
 int g_rec_gen = 0, g_rec_flush_interval = 128;   // --flush_interval, selfplay/main.cc:35
 bool g_init_state_sampling = true;
 float g_use_seen_state_prob = 0.5f, g_sel_mult_base = 0.0f, g_sel_mult_scale = 1.0f;
+float g_bias_cache_lambda = 0.0f, g_bias_cache_alpha = 0.8f;
+long g_last_bias_pruned = 0;
+double g_last_bias_adj = 0;
 int g_num_groups = 2;
 long g_step_limit = 0;   // > 0: the measured region ends after this many engine batches
 long g_last_reuse_added = 0, g_last_examples = 0;
@@ -588,6 +603,15 @@ void p3host_selfplay_set_policy(int init_state_sampling, float use_seen_state_pr
   g_sel_mult_base = sel_mult_base;
   g_sel_mult_scale = sel_mult_scale_factor;
 }
+// --bias_cache_lambda / --bias_cache_alpha of subsequent runs (selfplay/main.cc:58-61,257-258;
+// lambda 0 = off, the reference default; config/v4.json: 0.3 / 0.8).
+void p3host_selfplay_set_bias_cache(float lambda, float alpha) {
+  g_bias_cache_lambda = lambda;
+  g_bias_cache_alpha = alpha;
+}
+// bias-cache entries pruned / sum of |root adjustment| over the moves of the last run or game
+long p3host_selfplay_last_bias_pruned() { return g_last_bias_pruned; }
+double p3host_selfplay_last_bias_adj() { return g_last_bias_adj; }
 // Number of game groups of subsequent p3host_selfplay_run calls (>= 2).  Each group has its own
 // engine instance and is either being advanced on the host or evaluated on the GPU; with G
 // groups up to G - 1 forward passes are in flight while one group is on the host.
@@ -650,6 +674,8 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   cfg.use_seen_state_prob = g_use_seen_state_prob;
   cfg.sel_mult_base = g_sel_mult_base;
   cfg.sel_mult_scale_factor = g_sel_mult_scale;
+  cfg.bias_cache_lambda = g_bias_cache_lambda;
+  cfg.bias_cache_alpha = g_bias_cache_alpha;
   cfg.fork_params = ForkParams::ForReuse(g_use_seen_state_prob);
   auto reuse = std::make_unique<ReuseBuffer>(seed ^ 0x676f6578706c6f69ull);
   cfg.reuse = reuse.get();
@@ -737,6 +763,8 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
         t.moves += g->stats().moves; t.games += g->stats().games;
         t.evals += g->stats().evals; t.black_wins += g->stats().black_wins;
         t.cache_hits += g->stats().cache_hits;
+        t.bias_entries_pruned += g->stats().bias_entries_pruned;
+        t.bias_adj_abs_sum += g->stats().bias_adj_abs_sum;
       }
   };
 
@@ -807,6 +835,8 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     for (auto& H : halves) { out->batches += H.runs; out->gpu_seconds += H.gpu_seconds; }
     out->host_seconds = host_seconds;
     out->cache_hits = t.cache_hits - base.cache_hits;
+    g_last_bias_pruned = t.bias_entries_pruned - base.bias_entries_pruned;
+    g_last_bias_adj = t.bias_adj_abs_sum - base.bias_adj_abs_sum;
   }
   return rc;
 }
@@ -821,6 +851,8 @@ int p3host_selfplay_one_game(const char* engine_lib, const char* weights, int de
   cfg.selected_n = default_n; cfg.selected_k = default_k;
   cfg.max_moves = max_moves;
   cfg.init_state_sampling = false;   // one empty-board game at komi 7.5
+  cfg.bias_cache_lambda = g_bias_cache_lambda;
+  cfg.bias_cache_alpha = g_bias_cache_alpha;
   std::unique_ptr<Evaluator> ev;
   if (!engine_lib || !engine_lib[0]) {
     ev.reset(new NullEvaluator());
@@ -850,6 +882,8 @@ int p3host_selfplay_one_game(const char* engine_lib, const char* weights, int de
   if (bscore) *bscore = g.last_result().bscore;
   if (wscore) *wscore = g.last_result().wscore;
   if (evals) *evals = g.stats().evals;
+  g_last_bias_pruned = g.stats().bias_entries_pruned;
+  g_last_bias_adj = g.stats().bias_adj_abs_sum;
   return n_out;
 }
 

@@ -155,7 +155,24 @@ def selfplay_run(weights: str | None, num_games: int, num_threads: int, seconds:
     return st
 
 
-def selfplay_one_game(weights: str | None, default_n: int, default_k: int, max_moves: int, seed: int):
+def set_bias_cache(bias_cache_lambda: float = 0.0, bias_cache_alpha: float = 0.8) -> None:
+    """--bias_cache_lambda / --bias_cache_alpha of subsequent self-play runs (selfplay/main.cc:58-61);
+    lambda 0 = off (the reference default); config/v4.json (BASELINE configs[0]) sets 0.3 / 0.8."""
+    L = lib()
+    L.p3host_selfplay_set_bias_cache.argtypes = [C.c_float, C.c_float]
+    L.p3host_selfplay_set_bias_cache(bias_cache_lambda, bias_cache_alpha)
+
+
+def last_bias_counters():
+    """(bias-cache entries pruned, sum over moves of |root adjustment|) of the last run / game."""
+    L = lib()
+    L.p3host_selfplay_last_bias_pruned.restype = C.c_long
+    L.p3host_selfplay_last_bias_adj.restype = C.c_double
+    return L.p3host_selfplay_last_bias_pruned(), L.p3host_selfplay_last_bias_adj()
+
+
+def selfplay_one_game(weights: str | None, default_n: int, default_k: int, max_moves: int, seed: int,
+                      engine_lib: str | None = None):
     """One complete game on one thread; returns (moves, black_score, white_score, evals)."""
     L = lib()
     L.p3host_selfplay_one_game.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint64,
@@ -164,7 +181,7 @@ def selfplay_one_game(weights: str | None, default_n: int, default_k: int, max_m
     mv = np.zeros(1024, np.int32)
     b, w, ev = C.c_float(), C.c_float(), C.c_long()
     err = C.create_string_buffer(256)
-    elib = os.path.join(_HERE, "csrc", "libp3hip.so").encode() if weights else None
+    elib = (engine_lib or os.path.join(_HERE, "csrc", "libp3hip.so")).encode() if weights else None
     n = L.p3host_selfplay_one_game(elib, weights.encode() if weights else None, default_n, default_k,
                                    max_moves, seed, mv.ctypes.data, len(mv), C.byref(b), C.byref(w),
                                    C.byref(ev), err)

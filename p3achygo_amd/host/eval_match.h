@@ -9,7 +9,10 @@
 // leaves that the games whose side to move uses engine e want evaluated, runs engine e once,
 // and hands the results back — no thread per game, no slot signalling.
 #pragma once
+#include <cstdio>
+#include <fstream>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "features.h"
@@ -19,6 +22,29 @@
 namespace p3 {
 
 constexpr float kResignThreshold = -0.92f;   // eval.cc:28
+
+// core::RelativeElo (cc/core/elo.h:8-12) and the match summary of eval/main.cc:133-135,459-479.
+inline float RelativeElo(float winrate) { return 400 * std::log10(winrate / (1.0f - winrate)); }
+inline float ConfidenceDelta(float z_score, float num_sims, float wr) { return z_score * std::sqrt(wr * (1 - wr) / num_sims); }
+struct MatchSummary {
+  float winrate = 0, c95 = 0, rel_elo = 0, elo_c95 = 0;
+};
+inline MatchSummary SummarizeMatch(int num_cand_won, int num_games) {
+  MatchSummary m;
+  m.winrate = (float)num_cand_won / (float)num_games;
+  m.rel_elo = RelativeElo(m.winrate);
+  m.c95 = ConfidenceDelta(1.96f, (float)num_games, m.winrate);
+  m.elo_c95 = RelativeElo(.5f + m.c95);
+  return m;
+}
+// --res_write_path: the relative Elo as "%f" (eval/main.cc:473-477)
+inline bool WriteMatchResult(const std::string& path, float rel_elo) {
+  FILE* f = fopen(path.c_str(), "w");
+  if (!f) return false;
+  fprintf(f, "%f", rel_elo);
+  fclose(f);
+  return true;
+}
 
 struct EvalPlayerConfig {   // PlayerSearchConfig (player_config.h:20-108)
   int n = 128;                   // visit budget per move
@@ -37,7 +63,82 @@ struct EvalPlayerConfig {   // PlayerSearchConfig (player_config.h:20-108)
   CollisionPolicy collision_policy = CollisionPolicy::kAbort;
   CollisionDetector collision_detector = CollisionDetector::kNoOp;
   int max_collision_retries = 4;
+  DescentPolicy descent_policy = DescentPolicy::kDeterministic;   // "deterministic" | "bu_uct"
+  float max_o_ratio = 1.0f;
+  bool use_mcgs = false;                                          // McgsNodeTable for this player's tree
+  bool use_bias_cache = false;
+  float bias_cache_alpha = 0.8f, bias_cache_lambda = 0.4f;
+  int time_ms = 0;                                                // threaded driver only: time control
 };
+
+// ParsePlayerConfigFile (cc/eval/player_config.h:133-260): "key: value" lines, '#' comments.
+// Unknown keys are reported through *err (the reference LOG(FATAL)s on them).
+inline bool ParsePlayerConfig(const std::string& path, EvalPlayerConfig* cfg, std::string* err) {
+  std::ifstream in(path);
+  if (!in) { if (err) *err = "cannot open " + path; return false; }
+  auto trim = [](std::string x) {
+    const size_t b = x.find_first_not_of(" \t\r\n");
+    if (b == std::string::npos) return std::string();
+    return x.substr(b, x.find_last_not_of(" \t\r\n") - b + 1);
+  };
+  std::string line;
+  while (std::getline(in, line)) {
+    line = trim(line);
+    if (line.empty() || line[0] == '#') continue;
+    const size_t colon = line.find(':');
+    if (colon == std::string::npos) { if (err) *err = "no ':' in line: " + line; return false; }
+    const std::string key = trim(line.substr(0, colon)), val = trim(line.substr(colon + 1));
+    auto b = [&] { return val == "true" || val == "1"; };
+    if (key == "n") cfg->n = std::stoi(val);
+    else if (key == "num_threads_per_game") cfg->num_threads_per_game = std::stoi(val);
+    else if (key == "c_puct") cfg->c_puct = std::stof(val);
+    else if (key == "c_puct_visit_scaling") cfg->c_puct_visit_scaling = std::stof(val);
+    else if (key == "root_fpu") cfg->root_fpu = std::stof(val);
+    else if (key == "var_scale_cpuct") cfg->var_scale_cpuct = b();
+    else if (key == "var_scale_prior_visits") cfg->var_scale_prior_visits = std::stoi(val);
+    else if (key == "use_mcgs") cfg->use_mcgs = b();
+    else if (key == "use_bias_cache") cfg->use_bias_cache = b();
+    else if (key == "bias_cache_alpha") cfg->bias_cache_alpha = std::stof(val);
+    else if (key == "bias_cache_lambda") cfg->bias_cache_lambda = std::stof(val);
+    else if (key == "time_ms") cfg->time_ms = std::stoi(val);
+    else if (key == "vl_delta") cfg->vl_delta = std::stof(val);
+    else if (key == "max_collision_retries") cfg->max_collision_retries = std::stoi(val);
+    else if (key == "max_o_ratio") cfg->max_o_ratio = std::stof(val);
+    else if (key == "q_fn") {
+      if (val == "identity") cfg->q_fn = QFn::kIdentity;
+      else if (val == "virtual_loss") cfg->q_fn = QFn::kVirtualLoss;
+      else if (val == "virtual_loss_soft") cfg->q_fn = QFn::kVirtualLossSoft;
+      else { if (err) *err = "bad q_fn: " + val; return false; }
+    } else if (key == "n_fn") {
+      if (val == "identity") cfg->n_fn = NFn::kIdentity;
+      else if (val == "virtual_visit") cfg->n_fn = NFn::kVirtualVisit;
+      else { if (err) *err = "bad n_fn: " + val; return false; }
+    } else if (key == "collision_policy") {
+      if (val == "abort") cfg->collision_policy = CollisionPolicy::kAbort;
+      else if (val == "retry") cfg->collision_policy = CollisionPolicy::kRetry;
+      else if (val == "smart_retry") cfg->collision_policy = CollisionPolicy::kSmartRetry;
+      else { if (err) *err = "bad collision_policy: " + val; return false; }
+    } else if (key == "collision_detector") {
+      if (val == "noop") cfg->collision_detector = CollisionDetector::kNoOp;
+      else if (val == "n_in_flight") cfg->collision_detector = CollisionDetector::kNInFlight;
+      else if (val == "level_saturation") cfg->collision_detector = CollisionDetector::kLevelSaturation;
+      else if (val == "product") cfg->collision_detector = CollisionDetector::kProduct;
+      else { if (err) *err = "bad collision_detector: " + val; return false; }
+    } else if (key == "search_mode") {
+      if (val == "concurrent") cfg->search_mode = SearchMode::kConcurrent;
+      else if (val == "batch") cfg->search_mode = SearchMode::kBatch;
+      else { if (err) *err = "bad search_mode: " + val; return false; }
+    } else if (key == "descent_policy") {
+      if (val == "deterministic") cfg->descent_policy = DescentPolicy::kDeterministic;
+      else if (val == "bu_uct") cfg->descent_policy = DescentPolicy::kBuUct;
+      else { if (err) *err = "bad descent_policy: " + val; return false; }
+    } else {
+      if (err) *err = "unknown key: " + key;
+      return false;
+    }
+  }
+  return true;
+}
 
 class EvalGame {
  public:
@@ -45,7 +146,11 @@ class EvalGame {
       : id_(game_id), cur_is_black_(game_id % 2 == 0), max_moves_(max_moves), prob_(seed), game_(7.5f, true) {
     cfg_[0] = cur_is_black_ ? cur : cand;   // index 0 = black's player, 1 = white's
     cfg_[1] = cur_is_black_ ? cand : cur;
-    for (int s = 0; s < 2; ++s) tree_[s] = pool_[s].Create();
+    for (int s = 0; s < 2; ++s) {   // eval.cc:124-160: node table kind and bias cache per player
+      pool_[s].set_graph(cfg_[s].use_mcgs);
+      if (cfg_[s].use_bias_cache) bias_[s].reset(new BiasCache(cfg_[s].bias_cache_alpha, cfg_[s].bias_cache_lambda));
+      tree_[s] = pool_[s].GetOrCreate(game_.board().hash(), kBlack, false);
+    }
     BeginSearch();
   }
   bool done() const { return done_; }
@@ -82,9 +187,18 @@ class EvalGame {
     return (w == kBlack) == cur_is_black_ ? 1 : -1;
   }
   Color winner() const { return winner_; }
+  bool cur_is_black() const { return cur_is_black_; }
   bool resigned() const { return resigned_; }
   int num_moves() const { return game_.num_moves(); }
   long visits() const { return visits_; }
+  // the position / colour of evaluation i of the current Step() (for the caller's NN cache)
+  const Position& eval_position(int i) const { return parallel_ ? search_.eval_pos(i) : *puct_.eval_game(); }
+  Color eval_color_of(int i) const { return parallel_ ? search_.eval_color(i) : puct_.eval_color(); }
+  // a cached result is handed over without a symmetry (it was stored un-symmetrised)
+  void DeliverCached(int i, const p3hip_result& r) {
+    if (parallel_) search_.Deliver(i, r);
+    else puct_.Resume(r);
+  }
   long collisions() const { return collisions_; }
   const Game& game() const { return game_; }
 
@@ -104,6 +218,10 @@ class EvalGame {
     p.collision = cfg_[side].collision_policy;
     p.detector = cfg_[side].collision_detector;
     p.max_collision_retries = cfg_[side].max_collision_retries;
+    p.descent = cfg_[side].descent_policy;
+    p.max_o_ratio = cfg_[side].max_o_ratio;
+    p.bias_cache = bias_[side].get();
+    puct_.set_bias_cache(bias_[side].get());
     parallel_ = cfg_[side].num_threads_per_game > 1;   // UsesParallelSearch, eval.cc:99-101
     if (parallel_) {
       search_.Begin(&game_, &pool_[side], tree_[side], color_, p);
@@ -134,9 +252,10 @@ class EvalGame {
     color_ = Opp(color_);
     for (int s = 0; s < 2; ++s) {   // both trees follow the move (eval.cc:318-352)
       TreeNode* next = tree_[s]->child(MoveIdx(move));
-      if (!next) next = pool_[s].Create();
+      if (!next) next = pool_[s].GetOrCreate(game_.board().hash(), color_, game_.IsGameOver());
       pool_[s].Reap(next);
       tree_[s] = next;
+      if (bias_[s]) bias_[s]->PruneUnused();
     }
     if (game_.IsGameOver() || game_.num_moves() >= max_moves_) {
       game_.WriteResult();
@@ -153,6 +272,7 @@ class EvalGame {
   Probability prob_;
   Game game_;
   EvalPlayerConfig cfg_[2];
+  std::unique_ptr<BiasCache> bias_[2];   // before the pools: nodes release their entries first
   NodePool pool_[2];
   TreeNode* tree_[2];
   Color color_ = kBlack;

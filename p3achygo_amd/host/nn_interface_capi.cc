@@ -4,10 +4,12 @@
 #include <chrono>
 #include <random>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "../csrc/slot_state.h"
 #include "nn_interface.h"
+#include "threaded_search.h"
 
 using namespace p3;
 
@@ -282,6 +284,73 @@ int p3host_test_nn_async(int strategy, int tasks, int workers, int rounds, long*
     mask = eng->failures() | (error.load() ? 8 : 0);
     if (inferences_out) *inferences_out = nn.num_inferences();
   }
+  return mask;
+}
+
+// ---- the threaded concurrent search (threaded_search.h) over a kExplicit interface ------------
+// Plays `num_moves` moves from the empty board, each chosen by ThreadedSearch::Run with
+// `num_threads` worker threads and the given policies over the uniform NullEvaluator (graph != 0:
+// McgsNodeTable semantics; time_ms > 0: time control instead of the visit budget), re-using the
+// tree between moves, and checks after every search the invariants of search_test.cc:130-222:
+//   1  a node is still marked in flight,           2  n != 1 + sum of child visits on an inner node,
+//   4  the visit count is outside [budget, budget + threads),   8  the move is illegal,
+//   16 a child edge has visits but its node was never visited.
+// stats: [0] visits, [1] aborted, [2] collisions, [3] nodes alive at the end, [4] searches.
+int p3host_test_threaded_search(int num_threads, int visit_budget, int q_fn, int n_fn, int collision, int detector,
+                                int descent, int graph, int time_ms, int num_moves, uint64_t seed, long* stats) {
+  int mask = 0;
+  for (int i = 0; i < 5; ++i) stats[i] = 0;
+  NNInterface nn(num_threads, NNInterface::kTimeoutUs, 1 << 12, std::unique_ptr<Evaluator>(new NullEvaluator()),
+                 NNInterface::SignalKind::kExplicit, /*num_shared_search_tasks=*/1);
+  BiasCache bias(0.8f, 0.3f);
+  ThreadedSearch search(nn.MakeSlot(0), &bias);
+  NodePool pool(graph != 0);
+  Game game(7.5f, true);
+  Probability prob(seed);
+  TreeNode* root = pool.Create();
+  Color c = kBlack;
+  ThreadedSearch::Params p;
+  p.num_threads = num_threads;
+  p.total_visit_budget = time_ms > 0 ? (1 << 30) : visit_budget;
+  p.total_visit_time_ms = time_ms;
+  p.fns = VirtualFns{(QFn)q_fn, (NFn)n_fn, -1.5f};
+  p.collision = (CollisionPolicy)collision;
+  p.detector = (CollisionDetector)detector;
+  p.descent = (DescentPolicy)descent;
+  for (int m = 0; m < num_moves && !game.IsGameOver(); ++m) {
+    const int n_before = root->n;
+    const ThreadedSearch::Result r = search.Run(prob, game, &pool, root, c, p);
+    ++stats[4];
+    stats[0] += r.num_visits; stats[1] += r.num_aborted; stats[2] += r.num_collisions;
+    if (time_ms <= 0 && (r.num_visits < visit_budget || r.num_visits >= visit_budget + num_threads)) mask |= 4;
+    if (time_ms > 0 && (r.num_visits < 1 || r.time_ms > 20 * time_ms + 2000)) mask |= 4;
+    if (!game.IsValidMove(r.move, c)) mask |= 8;
+    // walk the tree from the root
+    std::vector<TreeNode*> work{root};
+    std::unordered_set<TreeNode*> seen;
+    while (!work.empty()) {
+      TreeNode* nd = work.back();
+      work.pop_back();
+      if (!seen.insert(nd).second) continue;
+      if (nd->n_in_flight.load() != 0) mask |= 1;
+      int cv = 0;
+      for (const ChildEdge& e : nd->children) {
+        cv += e.visits;
+        if (e.visits > 0 && e.node->n == 0) mask |= 16;
+        work.push_back(e.node);
+      }
+      if (nd->evaluated && !nd->is_terminal && nd->n > 0 && nd->n != 1 + cv) mask |= 2;
+    }
+    (void)n_before;
+    game.PlayMove(r.move, c);
+    c = Opp(c);
+    TreeNode* next = root->child(MoveIdx(r.move));
+    if (!next) next = pool.Create();
+    pool.Reap(next);
+    root = next;
+  }
+  stats[3] = (long)pool.Size();
+  nn.MakeSlot(0).UnregisterSearchTask();
   return mask;
 }
 

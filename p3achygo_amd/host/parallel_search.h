@@ -96,6 +96,42 @@ inline TopActions PuctTopScores(const TreeNode* node, const Board& board, Color 
   return top;
 }
 
+// BuUctDescentPolicy::Run (search.h:174-251): the PUCT ranking with children whose share of
+// in-flight descents O'(s, a) = sum_n_in_flights / (n + n_in_flight) exceeds `max_o` pushed out of
+// it; when that leaves nothing, the plain ranking.
+inline TopActions BuUctTopScores(const TreeNode* node, const Board& board, Color color, const PuctParams& pp,
+                                 bool is_root, const VirtualFns& vf, float max_o) {
+  float scores[kNumMoves];
+  PuctScoresAll(node, pp, is_root, scores, vf);
+  TopActions top, fallback;
+  top.fill({-1, -1000.0f});
+  fallback.fill({-1, -1000.0f});
+  auto ranking = [](const TopActions& t, float score) {
+    for (int r = 0; r < 4; ++r)
+      if (score >= t[r].second) return r;
+    return 4;
+  };
+  auto sift = [](TopActions& t, int r, std::pair<int, float> e) {
+    if (r < 0 || r >= 4) return;
+    for (int i = 3; i > r; --i) t[i] = t[i - 1];
+    t[r] = e;
+  };
+  for (int a = 0; a < kNumMoves; ++a) {
+    if (!board.IsValidMove(MoveLoc(a), color)) continue;
+    const int fr = ranking(fallback, scores[a]);
+    int r = ranking(top, scores[a]);
+    if (const TreeNode* child = node->child(a)) {
+      const float n = (float)child->n, nf = (float)child->n_in_flight.load(std::memory_order_acquire);
+      const float o = (float)child->sum_n_in_flights.load(std::memory_order_acquire) / (n + nf);
+      if (o > max_o) r = 4;
+    }
+    sift(fallback, fr, {a, scores[a]});
+    sift(top, r, {a, scores[a]});
+  }
+  return top[0].first >= 0 ? top : fallback;
+}
+
+enum class DescentPolicy : uint8_t { kDeterministic = 0, kBuUct = 1 };                    // search.h:26-29
 enum class SearchMode : uint8_t { kConcurrent = 0, kBatch = 1 };                           // Search::Mode
 enum class CollisionPolicy : uint8_t { kAbort = 0, kRetry = 1, kSmartRetry = 2 };          // search.h:28-32
 enum class CollisionDetector : uint8_t { kNoOp = 0, kNInFlight = 1, kLevelSaturation = 2, kProduct = 3 };   // :34-39
@@ -114,6 +150,9 @@ struct ParallelSearchParams {   // Search::Params (search.h:92-107)
   CollisionPolicy collision = CollisionPolicy::kAbort;
   int max_collision_retries = 4;
   CollisionDetector detector = CollisionDetector::kNoOp;
+  DescentPolicy descent = DescentPolicy::kDeterministic;   // descent_policy_kind (concurrent mode)
+  float max_o_ratio = 0.8f;                                  // BuUct: max_o = ratio * (workers - 1) / 2, search.cc:651-653
+  BiasCache* bias_cache = nullptr;                           // optional (Search's second constructor)
 };
 struct ParallelSearchResult {   // Search::Result
   Loc move = kPassLoc;
@@ -150,6 +189,7 @@ class BatchSearch {
           return 1;
         case State::kRootEvalWait:
           EvaluateRoot(pending_[0], root_, color_);
+          AssignBiasCacheEntry(p_.bias_cache, root_pos_, root_);   // search.cc:787
           state_ = State::kRound;
           break;
         case State::kRound:
@@ -208,12 +248,17 @@ class BatchSearch {
     w.pos = root_pos_;
     w.path.clear();
     Color c = color_;
-    in_flight(root_)++;
+    root_->sum_n_in_flights += in_flight(root_)++;   // search.cc:110-113
     TreeNode* cur = root_;
-    auto collide = [&]() {
-      for (PathElem& e : w.path) in_flight(e.node)--;
+    auto collide = [&]() {   // on_collision, search.cc:96-106
+      for (PathElem& e : w.path) {
+        const int old = in_flight(e.node)--;
+        e.node->sum_n_in_flights -= old - 1;
+      }
       return false;
     };
+    const bool bu_uct = p_.mode == SearchMode::kConcurrent && p_.descent == DescentPolicy::kBuUct;
+    const float max_o = p_.max_o_ratio * (float)(p_.batch - 1) / 2.0f;
     for (size_t idx = 0;; ++idx) {
       if (!cur->evaluated) {   // a leaf claimed earlier in this round
         w.path.push_back({cur, -1, {}});
@@ -222,7 +267,11 @@ class BatchSearch {
       int action;
       TopActions top;
       if (idx < prefix.size()) { action = prefix[idx].action; top = prefix[idx].top; }
-      else { top = PuctTopScores(cur, w.pos.board, c, p_.puct, cur == root_, fns); action = top[0].first; }
+      else {
+        top = bu_uct ? BuUctTopScores(cur, w.pos.board, c, p_.puct, cur == root_, fns, max_o)
+                     : PuctTopScores(cur, w.pos.board, c, p_.puct, cur == root_, fns);
+        action = top[0].first;
+      }
       if (action < 0) action = kPassEncoding;   // no legal scored move: pass is always legal
       w.pos.PlayMove(MoveLoc(action), c);
       c = Opp(c);
@@ -231,14 +280,24 @@ class BatchSearch {
       int child_in_flight;
       if (child) {
         child_in_flight = in_flight(child)++;
+        child->sum_n_in_flights += child_in_flight;
       } else {
-        child = pool_->Create();
+        // leaf case (search.cc:156-177).  In graph mode the table may hand back a node another
+        // path already owns: claimed in this round -> collision; evaluated -> keep descending.
+        child = pool_->GetOrCreate(w.pos.board.hash(), c, w.pos.IsGameOver());
         child->color_to_move = c;
-        child->is_terminal = w.pos.IsGameOver();
+        if (w.pos.IsGameOver()) child->is_terminal = true;
         child_in_flight = in_flight(child)++;
+        child->sum_n_in_flights += child_in_flight;
         cur->children.push_back(ChildEdge{(int16_t)action, 0, child});
-        cur = child;   // a new node: claimed by this descent
-        break;
+        if (!child->evaluated) {
+          if (child_in_flight > 0) {
+            w.path.push_back({child, -1, {}});
+            return collide();
+          }
+          cur = child;   // a new node: claimed by this descent
+          break;
+        }
       }
       if (p_.mode == SearchMode::kConcurrent && DetectorFires(child_in_flight, (int)w.path.size() + 1)) {
         w.path.push_back({child, -1, {}});
@@ -379,7 +438,9 @@ class BatchSearch {
       if (w.pos.IsGameOver()) {
         Scores s = w.pos.GetScores();
         EvaluateTerminal(s, leaf, w.leaf_color, color_, root_->init_score_est);
+        leaf->evaluated = true;
       }
+      AssignBiasCacheEntry(p_.bias_cache, w.pos, leaf);   // search.cc:251
       ++res_.num_visits;
     }
     // deepest first; a node is finalised on the last entry that passes through it
@@ -396,7 +457,7 @@ class BatchSearch {
           node->w = node->v = node->init_util_est;
           node->w_outcome = node->v_outcome = node->init_outcome_est;
         } else {
-          RecomputeNodeStats(node);
+          RecomputeNodeStats(node, UpdateAndFetchObsBias(p_.bias_cache, node));   // search.cc:277-279
         }
       }
     }
@@ -414,7 +475,7 @@ class BatchSearch {
     state_ = State::kDone;
   }
 
-  int& in_flight(TreeNode* n) { return n->n_in_flight; }
+  std::atomic<int>& in_flight(TreeNode* n) { return n->n_in_flight; }
 
   struct BackupElem { int depth; TreeNode* node; int action; bool is_leaf; };
   static constexpr int kMaxBatch = 64;

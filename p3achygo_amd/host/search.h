@@ -18,10 +18,13 @@
 // Tree nodes keep children sparsely (a search at n = 32 touches a handful of the 362 moves).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <array>
 #include <cmath>
 #include <memory>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/p3hip.h"
@@ -46,7 +49,7 @@ struct ChildEdge {
 };
 
 struct TreeNode {                                        // cc/mcts/tree.h:21-91
-  bool evaluated = false;   // TreeNodeState::kNnEvaluated
+  std::atomic<bool> evaluated{false};   // TreeNodeState::kNnEvaluated (read by concurrent descents)
   bool is_terminal = false;
   Color color_to_move = kEmpty;
   int n = 0;
@@ -61,8 +64,38 @@ struct TreeNode {                                        // cc/mcts/tree.h:21-91
   float move_logits[kNumMoves], move_probs[kNumMoves], opt_probs[kNumMoves];
   float init_outcome_est = 0, init_score_est = 0, init_score_var = 0, init_util_est = 0, init_err_est = 0;
   uint32_t mark = 0;  // NodePool::Reap
-  int n_in_flight = 0;  // descents of the current round through this node (parallel_search.h)
+  // descents of the current round through this node, and the running sum of the values it had
+  // when each descent arrived (tree.h:90-92; BuUct's O statistic) — atomics: the threaded search
+  // (threaded_search.h) updates them from several workers at once
+  std::atomic<int> n_in_flight{0}, sum_n_in_flights{0};
+  std::mutex mu;        // node lock of the threaded search: child choice + child creation, n / visits in backup
   BiasNodeState bias;   // bias_cache_entry / last_obs_bias_term / last_weight_term, tree.h:83-86
+  // graph-search identity (McgsNodeTable's key, node_table.h:77-118)
+  uint64_t board_hash = 0;
+  bool in_table = false;
+
+  // back to a freshly constructed node (nodes are recycled by NodePool)
+  void Reset() {
+    bias.Release();
+    evaluated.store(false, std::memory_order_relaxed);
+    is_terminal = false;
+    color_to_move = kEmpty;
+    n = 0;
+    w = v = v_var = 0;
+    v_m3 = 0;
+    std::fill(std::begin(v_categorical), std::end(v_categorical), 0u);
+    w_outcome = v_outcome = v_outcome_var = 0;
+    v_outcome_m3 = 0;
+    score = v_err = 0;
+    max_child_n = 0;
+    children.clear();
+    init_outcome_est = init_score_est = init_score_var = init_util_est = init_err_est = 0;
+    mark = 0;
+    n_in_flight.store(0, std::memory_order_relaxed);
+    sum_n_in_flights.store(0, std::memory_order_relaxed);
+    board_hash = 0;
+    in_table = false;
+  }
 
   ChildEdge* edge(int a) {
     for (auto& e : children)
@@ -82,15 +115,20 @@ inline float QOutcome(const TreeNode* n, int a) { const TreeNode* c = n->child(a
 inline float SumChildrenN(const TreeNode* n) { return n ? (float)(n->n - 1) : 0; }
 inline float MaxN(const TreeNode* n) { return n ? (float)n->max_child_n : 0; }
 
-// MctsNodeTable (cc/mcts/node_table.h:49-76): fresh node per request, Reap keeps what is
-// reachable from the new root (node_table.cc:12-40).
+// MctsNodeTable / McgsNodeTable (cc/mcts/node_table.h:40-118, node_table.cc:12-68).  Tree mode
+// hands out a fresh node per request; graph mode (Monte-Carlo graph search) returns the one node
+// of a (board hash, colour to move, terminal) triple, so transpositions share statistics.  Reap
+// keeps what is reachable from the new root.  GetOrCreateGuarded serialises concurrent callers.
 class NodePool {
  public:
+  explicit NodePool(bool graph = false) : graph_(graph) {}
+  bool is_graph() const { return graph_; }
+  void set_graph(bool graph) { graph_ = graph; }   // only while the pool is empty
   TreeNode* Create() {
     if (!free_.empty()) {
       TreeNode* n = free_.back();
       free_.pop_back();
-      *n = TreeNode();
+      n->Reset();
       live_.push_back(n);
       return n;
     }
@@ -98,7 +136,25 @@ class NodePool {
     live_.push_back(owned_.back().get());
     return live_.back();
   }
+  TreeNode* GetOrCreate(uint64_t board_hash, Color color_to_move, bool is_terminal) {
+    if (!graph_) return Create();
+    const Key key{board_hash, color_to_move, is_terminal};
+    auto it = table_.find(key);
+    if (it != table_.end()) return it->second;
+    TreeNode* n = Create();
+    n->board_hash = board_hash;
+    n->color_to_move = color_to_move;
+    n->is_terminal = is_terminal;
+    n->in_table = true;
+    table_.emplace(key, n);
+    return n;
+  }
+  TreeNode* GetOrCreateGuarded(uint64_t board_hash, Color color_to_move, bool is_terminal) {
+    std::lock_guard<std::mutex> l(mu_);
+    return GetOrCreate(board_hash, color_to_move, is_terminal);
+  }
   int Reap(TreeNode* new_root) {
+    std::lock_guard<std::mutex> l(mu_);
     ++epoch_;
     std::vector<TreeNode*> work;
     if (new_root) work.push_back(new_root);
@@ -113,8 +169,12 @@ class NodePool {
     int reaped = 0;
     size_t keep = 0;
     for (TreeNode* n : live_) {
-      if (n->mark == epoch_) live_[keep++] = n;
-      else { n->bias.Release(); free_.push_back(n); ++reaped; }   // ~TreeNode, tree.h:23-32
+      if (n->mark == epoch_) { live_[keep++] = n; continue; }
+      if (n->in_table) table_.erase(Key{n->board_hash, n->color_to_move, n->is_terminal});
+      n->bias.Release();   // ~TreeNode, tree.h:23-32
+      n->in_table = false;
+      free_.push_back(n);
+      ++reaped;
     }
     live_.resize(keep);
     return reaped;
@@ -124,8 +184,22 @@ class NodePool {
   ~NodePool() { for (TreeNode* n : live_) n->bias.Release(); }
 
  private:
+  struct Key {
+    uint64_t hash;
+    Color color;
+    bool terminal;
+    bool operator==(const Key& o) const { return hash == o.hash && color == o.color && terminal == o.terminal; }
+  };
+  struct KeyHash {
+    size_t operator()(const Key& k) const {
+      return (size_t)(k.hash ^ ((uint64_t)(uint8_t)k.color << 1) ^ (uint64_t)k.terminal) * 0x9e3779b97f4a7c15ull;
+    }
+  };
+  bool graph_;
   std::vector<std::unique_ptr<TreeNode>> owned_;
   std::vector<TreeNode*> live_, free_;
+  std::unordered_map<Key, TreeNode*, KeyHash> table_;
+  std::mutex mu_;
   uint32_t epoch_ = 0;
 };
 
@@ -158,7 +232,6 @@ inline void InitFields(const p3hip_result& r, TreeNode* node, Color color_to_mov
   node->init_score_est = score_est;
   node->init_score_var = score_sq - score_est * score_est;
   node->init_err_est = std::sqrt(r.err2_outcome);
-  node->evaluated = true;
 }
 
 inline void EvaluateRoot(const p3hip_result& r, TreeNode* node, Color c) {   // :131-150
@@ -170,6 +243,7 @@ inline void EvaluateRoot(const p3hip_result& r, TreeNode* node, Color c) {   // 
   node->v_err = node->init_err_est;
   int b = std::clamp((int)((node->init_util_est + 1.0f) / kBucketRange), 0, kNumVBuckets - 1);
   node->v_categorical[b] += 1;
+  node->evaluated.store(true, std::memory_order_release);   // last: concurrent descents read the fields above
 }
 
 inline void EvaluateLeaf(const p3hip_result& r, TreeNode* node, Color c, Color root_color,
@@ -177,6 +251,7 @@ inline void EvaluateLeaf(const p3hip_result& r, TreeNode* node, Color c, Color r
   InitFields(r, node, c);
   root_score_est *= c == root_color ? 1.0f : -1.0f;
   node->init_util_est = node->init_outcome_est + ScoreTransform(kDefaultScoreWeight, node->init_score_est, root_score_est);
+  node->evaluated.store(true, std::memory_order_release);
 }
 
 inline void EvaluateTerminal(const Scores& s, TreeNode* node, Color c, Color root_color,
@@ -566,10 +641,12 @@ class GumbelSearch {
     round_open_ = false;
   }
 
-  TreeNode* GetOrCreateChild(TreeNode* parent, int a) {
+  // `pos` = the position after action `a`, `next` = its side to move (graph search shares the node
+  // of a transposition: NodeTable::GetOrCreate, gumbel.cc:700-705)
+  TreeNode* GetOrCreateChild(TreeNode* parent, int a, const Position& pos, Color next) {
     ChildEdge* e = parent->edge(a);
     if (!e) {
-      parent->children.push_back(ChildEdge{(int16_t)a, 0, pool_->Create()});
+      parent->children.push_back(ChildEdge{(int16_t)a, 0, pool_->GetOrCreate(pos.board.hash(), next, pos.IsGameOver())});
       e = &parent->children.back();
     }
     return e->node;
@@ -581,7 +658,7 @@ class GumbelSearch {
     const int a0 = gm_[cand_].enc;
     search_game_ = root_pos_;
     search_game_.PlayMove(MoveLoc(a0), color_);
-    TreeNode* child = GetOrCreateChild(root_, a0);
+    TreeNode* child = GetOrCreateChild(root_, a0, search_game_, Opp(color_));
     path_.clear();
     path_.push_back(PathEntry{-1, child});
     Color c = Opp(color_);
@@ -593,7 +670,7 @@ class GumbelSearch {
       int a = PuctTopMove(node, search_game_.board, c, pp);
       if (a < 0) a = kPassEncoding;
       search_game_.PlayMove(MoveLoc(a), c);
-      TreeNode* nx = GetOrCreateChild(node, a);
+      TreeNode* nx = GetOrCreateChild(node, a, search_game_, Opp(c));
       path_.back().action = a;
       path_.push_back(PathEntry{-1, nx});
       c = Opp(c);
@@ -633,7 +710,7 @@ class GumbelSearch {
       first = false;
       if (a < 0) a = kPassEncoding;
       search_game_.PlayMove(MoveLoc(a), c);
-      TreeNode* nx = GetOrCreateChild(node, a);
+      TreeNode* nx = GetOrCreateChild(node, a, search_game_, Opp(c));
       path_.back().action = a;
       path_.push_back(PathEntry{-1, nx});
       c = Opp(c);
@@ -717,7 +794,7 @@ class GumbelSearch {
     node->n += 1;
     ChildEdge* e = node->edge(a);
     e->visits += 1;
-    if (bias_cache_) {
+    if (bias_cache_ || pool_->is_graph()) {
       // use_idempotent_updates (gumbel.cc:446-448,608-610,770-777): every statistic is recomputed
       // from the children with the cache's observed bias taken off the node's own estimate; the
       // value histogram stays incremental as in the reference

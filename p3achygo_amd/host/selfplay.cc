@@ -158,18 +158,25 @@ struct GameStats {
 // selfplay/main.cc:177).  Results are stored un-symmetrised, as the reference does.
 class EvalCache {
  public:
-  explicit EvalCache(int capacity) : cap_(capacity) {}
+  // num_last_moves: how many of the last moves are part of the key (NNInterface::
+  // SetNumCacheLastMoves; self-play 1, the default used by cc/eval 5)
+  explicit EvalCache(int capacity, int num_last_moves = 1) : cap_(capacity), nlast_(num_last_moves) {}
   struct Key {
     uint64_t hash;
-    int last_i, last_j;
+    Loc last[5];
     float komi;
     Color color;
     bool operator==(const Key& o) const {
-      return hash == o.hash && last_i == o.last_i && last_j == o.last_j && komi == o.komi && color == o.color;
+      if (hash != o.hash || komi != o.komi || color != o.color) return false;
+      for (int i = 0; i < 5; ++i)
+        if (last[i] != o.last[i]) return false;
+      return true;
     }
   };
-  static Key MakeKey(const Position& pos, Color c) {
-    return Key{pos.board.hash(), pos.last[4].loc.i, pos.last[4].loc.j, pos.komi(), c};
+  Key MakeKey(const Position& pos, Color c) const {   // NNInterface::MakeKey, nn_interface.cc:92-106
+    Key k{pos.board.hash(), {kNoopLoc, kNoopLoc, kNoopLoc, kNoopLoc, kNoopLoc}, pos.komi(), c};
+    for (int i = 5 - nlast_; i < 5; ++i) k.last[i] = pos.last[i].loc;
+    return k;
   }
   const p3hip_result* Find(const Key& k) {
     for (auto& e : entries_)
@@ -191,7 +198,7 @@ class EvalCache {
 
  private:
   struct Entry { Key key; uint64_t stamp; p3hip_result result; };
-  int cap_;
+  int cap_, nlast_;
   uint64_t clock_ = 0;
   std::vector<Entry> entries_;
 };
@@ -239,7 +246,7 @@ class GameRunner {
  private:
   // true: *f holds a position for the engine; false: served from the cache
   bool RequestEval(const Position& pos, Color c, p3hip_features* f) {
-    pending_key_ = EvalCache::MakeKey(pos, c);
+    pending_key_ = cache_.MakeKey(pos, c);
     if (const p3hip_result* hit = cache_.Find(pending_key_)) {   // nn_interface.cc:112-118
       ++stats_.cache_hits;
       Resume(*hit);
@@ -891,6 +898,7 @@ int p3host_selfplay_one_game(const char* engine_lib, const char* weights, int de
 
 // ---- evaluation matches (cc/eval) ------------------------------------------------------------
 #include "eval_match.h"
+#include "threaded_search.h"
 
 extern "C" {
 
@@ -898,30 +906,98 @@ struct p3host_eval_stats {
   int games, cur_wins, cand_wins, draws, resignations;
   long moves, visits, collisions, positions, batches;
   double seconds;
+  long cache_hits;                        // evaluations served by the NN cache (not in `positions`)
+  float winrate, c95, rel_elo, elo_c95;   // cand's win rate +- 95 %, relative Elo +- (eval/main.cc:459-471)
 };
 
-// Plays `num_games` evaluation games between two networks with the batch parallel search
-// (eval.cc:103-518).  engine_lib NULL/"" = NullEvaluator for both players.  One engine
-// instance per player, batch = num_games * leaves_per_round slots.
 static int g_eval_mode = 0, g_eval_qfn = 2, g_eval_nfn = 1, g_eval_collision = 0, g_eval_detector = 0;
+static int g_eval_descent = 0, g_eval_mcgs = 0, g_eval_cache_per_game = 256;
+static float g_eval_max_o = 1.0f, g_eval_bias_lambda = 0.0f, g_eval_bias_alpha = 0.8f;
+static std::string g_eval_cur_cfg, g_eval_cand_cfg, g_eval_recorder_dir, g_eval_res_path;
 // Parallel-search knobs of subsequent p3host_eval_match calls (defaults = player_config.h:76-108:
 // concurrent rounds, virtual_loss_soft, virtual_visit, abort, noop).
 void p3host_eval_set_search(int mode, int q_fn, int n_fn, int collision, int detector) {
   g_eval_mode = mode; g_eval_qfn = q_fn; g_eval_nfn = n_fn; g_eval_collision = collision; g_eval_detector = detector;
 }
+// descent policy (0 deterministic, 1 bu_uct + max_o_ratio), graph search, bias cache (lambda 0 = off)
+// and NN-cache entries per game and player (--cache_size; 0 = off) of subsequent matches
+void p3host_eval_set_search_ex(int descent, float max_o_ratio, int use_mcgs, float bias_lambda, float bias_alpha,
+                               int cache_entries_per_game) {
+  g_eval_descent = descent; g_eval_max_o = max_o_ratio; g_eval_mcgs = use_mcgs;
+  g_eval_bias_lambda = bias_lambda; g_eval_bias_alpha = bias_alpha;
+  g_eval_cache_per_game = cache_entries_per_game;
+}
+// --cur_config / --cand_config player files ("" = none), --recorder_path (SGFs of the games under
+// <dir>/sgf; "" = none), --res_write_path (relative Elo; "" = none) of subsequent matches
+void p3host_eval_set_paths(const char* cur_config, const char* cand_config, const char* recorder_dir,
+                           const char* res_write_path) {
+  g_eval_cur_cfg = cur_config ? cur_config : "";
+  g_eval_cand_cfg = cand_config ? cand_config : "";
+  g_eval_recorder_dir = recorder_dir ? recorder_dir : "";
+  g_eval_res_path = res_write_path ? res_write_path : "";
+}
 
+static bool MakeEvalPlayerConfigs(int visits_per_move, int leaves_per_round, EvalPlayerConfig pc[2], char* err) {
+  EvalPlayerConfig base;
+  base.n = visits_per_move;
+  base.num_threads_per_game = leaves_per_round;
+  base.search_mode = (SearchMode)g_eval_mode;
+  base.q_fn = (QFn)g_eval_qfn;
+  base.n_fn = (NFn)g_eval_nfn;
+  base.collision_policy = (CollisionPolicy)g_eval_collision;
+  base.collision_detector = (CollisionDetector)g_eval_detector;
+  base.descent_policy = (DescentPolicy)g_eval_descent;
+  base.max_o_ratio = g_eval_max_o;
+  base.use_mcgs = g_eval_mcgs != 0;
+  base.use_bias_cache = g_eval_bias_lambda > 0.0f;
+  base.bias_cache_lambda = g_eval_bias_lambda;
+  base.bias_cache_alpha = g_eval_bias_alpha;
+  pc[0] = pc[1] = base;
+  std::string e;
+  if (!g_eval_cur_cfg.empty() && !ParsePlayerConfig(g_eval_cur_cfg, &pc[0], &e)) { if (err) snprintf(err, 256, "cur config: %s", e.c_str()); return false; }
+  if (!g_eval_cand_cfg.empty() && !ParsePlayerConfig(g_eval_cand_cfg, &pc[1], &e)) { if (err) snprintf(err, 256, "cand config: %s", e.c_str()); return false; }
+  return true;
+}
+
+// match bookkeeping shared by both drivers: results, Elo, result file, SGF batch
+struct EvalGameOutcome { int cur_result; bool resigned; Color winner; std::string sgf; };
+static void FinishEvalMatch(const std::vector<EvalGameOutcome>& games, p3host_eval_stats* out) {
+  for (const auto& g : games) {
+    out->cur_wins += g.cur_result > 0;
+    out->cand_wins += g.cur_result < 0;
+    out->draws += g.cur_result == 0;
+    out->resignations += g.resigned;
+  }
+  out->games = (int)games.size();
+  const MatchSummary m = SummarizeMatch(out->cand_wins, out->games);
+  out->winrate = m.winrate; out->c95 = m.c95; out->rel_elo = m.rel_elo; out->elo_c95 = m.elo_c95;
+  if (!g_eval_res_path.empty()) WriteMatchResult(g_eval_res_path, m.rel_elo);
+  if (!g_eval_recorder_dir.empty()) {   // GameRecorder::Create(recorder_path, ..., "EVAL_<cur>_<cand>"), eval/main.cc:418-422
+    ::mkdir(g_eval_recorder_dir.c_str(), 0755);
+    ::mkdir((g_eval_recorder_dir + "/sgf").c_str(), 0755);
+    SgfRecorder rec(g_eval_recorder_dir + "/sgf", 0, "EVAL_cur_cand");
+    for (const auto& g : games) rec.RecordGame(g.sgf);
+    rec.Flush();
+  }
+}
+static std::string EvalGameSgf(const Game& game, bool cur_is_black, bool resigned, Color winner) {
+  Game::Result r = game.result();
+  if (resigned) { r = Game::Result(); r.winner = winner; r.by_resign = true; }
+  return SgfGameString(game.komi(), r, game.moves(), Game::kMoveOffset, cur_is_black ? "cur" : "cand",
+                       cur_is_black ? "cand" : "cur");
+}
+
+// Plays `num_games` evaluation games between two networks with the batch parallel search
+// (eval.cc:103-518).  engine_lib NULL/"" = NullEvaluator for both players.  One engine
+// instance per player, batch = num_games * leaves_per_round slots; every game keeps an NN cache
+// per player (NNKey with five last moves, nn_interface.cc:92-132), so a position the search
+// reaches again — in a later move's search, or through the other player's tree — costs no slot.
 int p3host_eval_match(const char* engine_lib, const char* cur_weights, const char* cand_weights, int device,
                       int num_games, int visits_per_move, int leaves_per_round, int max_moves, int num_threads,
                       uint64_t seed, p3host_eval_stats* out, char* err) {
-  EvalPlayerConfig pc;
-  pc.n = visits_per_move;
-  pc.num_threads_per_game = leaves_per_round;
-  pc.search_mode = (SearchMode)g_eval_mode;
-  pc.q_fn = (QFn)g_eval_qfn;
-  pc.n_fn = (NFn)g_eval_nfn;
-  pc.collision_policy = (CollisionPolicy)g_eval_collision;
-  pc.collision_detector = (CollisionDetector)g_eval_detector;
-  const int slots = num_games * leaves_per_round;
+  EvalPlayerConfig pc[2];
+  if (!MakeEvalPlayerConfigs(visits_per_move, leaves_per_round, pc, err)) return 3;
+  const int slots = num_games * std::max(pc[0].num_threads_per_game, pc[1].num_threads_per_game);
   std::unique_ptr<Evaluator> ev[2];
   const bool use_null = !engine_lib || !engine_lib[0];
   for (int e = 0; e < 2; ++e) {
@@ -938,14 +1014,37 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
   }
   std::vector<std::unique_ptr<EvalGame>> games;
   for (int g = 0; g < num_games; ++g)
-    games.emplace_back(new EvalGame(g, pc, pc, max_moves, seed * 0x9E3779B97F4A7C15ull + (uint64_t)g * 0xBF58476D1CE4E5B9ull));
+    games.emplace_back(new EvalGame(g, pc[0], pc[1], max_moves, seed * 0x9E3779B97F4A7C15ull + (uint64_t)g * 0xBF58476D1CE4E5B9ull));
+  std::vector<EvalCache> caches;   // [game * 2 + engine]
+  for (int g = 0; g < 2 * num_games; ++g) caches.emplace_back(g_eval_cache_per_game, 5);
   WorkerPool pool(num_threads > 0 ? num_threads : 1);
-  std::vector<int> want(num_games, 0), base(num_games, 0);
-  std::vector<p3hip_features> feats(slots);
+  std::vector<int> want(num_games, 0), base(num_games, 0), need(num_games, 0);
+  std::vector<std::vector<int>> slot_of(num_games);          // evaluation i of game g -> engine slot offset, -1 = cached
+  std::vector<std::vector<EvalCache::Key>> key_of(num_games);
+  std::vector<p3hip_features> feats(2 * (size_t)slots);
   long positions = 0, batches = 0;
+  std::atomic<long> cache_hits{0};
   const auto t0 = std::chrono::steady_clock::now();
-  // every game starts wanting evaluations from the engine of its side to move
-  pool.ParallelFor(num_games, [&](int g) { want[g] = games[g]->Step(); });
+  // Advances game g until it wants evaluations the cache cannot answer (or has finished).
+  auto advance = [&](int g) {
+    for (;;) {
+      want[g] = games[g]->Step();
+      need[g] = 0;
+      if (want[g] <= 0) return;
+      const int e = games[g]->active_engine();
+      EvalCache& cache = caches[2 * g + e];
+      slot_of[g].assign(want[g], -1);
+      key_of[g].resize(want[g]);
+      for (int i = 0; i < want[g]; ++i) {
+        key_of[g][i] = cache.MakeKey(games[g]->eval_position(i), games[g]->eval_color_of(i));
+        if (!cache.Find(key_of[g][i])) slot_of[g][i] = need[g]++;
+      }
+      if (need[g] > 0) return;
+      for (int i = 0; i < want[g]; ++i) games[g]->DeliverCached(i, *cache.Find(key_of[g][i]));   // all cached
+      cache_hits.fetch_add(want[g], std::memory_order_relaxed);
+    }
+  };
+  pool.ParallelFor(num_games, [&](int g) { advance(g); });
   std::vector<int> eng_of(num_games, -1);
   for (;;) {
     // Every game wants leaves from the engine of its side to move: fill both engines' batches,
@@ -958,17 +1057,17 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
       const int e = games[g]->active_engine();
       eng_of[g] = e;
       base[g] = total[e];
-      total[e] += want[g];
+      total[e] += need[g];
     }
     if (total[0] + total[1] == 0) break;
     pool.ParallelFor(num_games, [&](int g) {
       if (base[g] < 0) return;
       const int e = eng_of[g];
-      // the two engines' slot ranges share `feats`: engine 1's rows start after engine 0's
-      p3hip_features* f = &feats[(e == 0 ? 0 : total[0]) + base[g]];
+      p3hip_features* f = &feats[(size_t)e * slots + base[g]];
       for (int i = 0; i < want[g]; ++i) {
-        games[g]->FillEval(i, f + i);
-        ev[e]->Load(base[g] + i, f[i]);
+        if (slot_of[g][i] < 0) continue;
+        games[g]->FillEval(i, f + slot_of[g][i]);
+        ev[e]->Load(base[g] + slot_of[g][i], f[slot_of[g][i]]);
       }
     });
     bool ok[2] = {true, true};
@@ -985,31 +1084,161 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
     pool.ParallelFor(num_games, [&](int g) {
       if (base[g] < 0) return;
       const int e = eng_of[g];
+      EvalCache& cache = caches[2 * g + e];
       p3hip_result r;
       for (int i = 0; i < want[g]; ++i) {
-        ev[e]->Get(base[g] + i, r);
-        games[g]->Deliver(i, r);
+        if (slot_of[g][i] < 0) {
+          games[g]->DeliverCached(i, *cache.Find(key_of[g][i]));
+          cache_hits.fetch_add(1, std::memory_order_relaxed);
+          continue;
+        }
+        ev[e]->Get(base[g] + slot_of[g][i], r);
+        games[g]->Deliver(i, r);   // un-symmetrises r in place
+        cache.Insert(key_of[g][i], r);
       }
-      want[g] = games[g]->Step();
+      advance(g);
     });
   }
   if (out) {
     std::memset(out, 0, sizeof *out);
-    out->games = num_games;
+    std::vector<EvalGameOutcome> outcomes;
     for (auto& g : games) {
-      const int r = g->cur_result();
-      out->cur_wins += r > 0;
-      out->cand_wins += r < 0;
-      out->draws += r == 0;
-      out->resignations += g->resigned();
+      outcomes.push_back({g->cur_result(), g->resigned(), g->winner(),
+                          EvalGameSgf(g->game(), g->cur_is_black(), g->resigned(), g->winner())});
       out->moves += g->num_moves();
       out->visits += g->visits();
       out->collisions += g->collisions();
     }
+    FinishEvalMatch(outcomes, out);
     out->positions = positions;
     out->batches = batches;
+    out->cache_hits = cache_hits.load();
     out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
+  return 0;
+}
+
+// The reference's own shape of the match (eval/main.cc:380-452, eval.cc:103-518): one OS thread
+// per game, each player's engine behind its own NNInterface with kExplicit signalling,
+// num_shared_search_tasks = num_games, batch = num_games * threads_per_game slots and the
+// per-thread NN cache on (cache_size entries in total per interface), the side to move running
+// the threaded mcts::Search (threaded_search.h) on slot range [game * T, (game + 1) * T).
+int p3host_eval_match_threads(const char* engine_lib, const char* cur_weights, const char* cand_weights, int device,
+                              int num_games, int visits_per_move, int threads_per_game, int max_moves,
+                              long cache_size, uint64_t seed, p3host_eval_stats* out, char* err) {
+  EvalPlayerConfig pc[2];
+  if (!MakeEvalPlayerConfigs(visits_per_move, threads_per_game, pc, err)) return 3;
+  const bool use_null = !engine_lib || !engine_lib[0];
+  std::unique_ptr<NNInterface> nn[2];
+  for (int e = 0; e < 2; ++e) {
+    const int batch = num_games * pc[e].num_threads_per_game;
+    std::unique_ptr<Evaluator> ev;
+    if (use_null) {
+      ev.reset(new NullEvaluator());
+    } else {
+      auto* h = new HipEvaluator();
+      ev.reset(h);
+      if (!h->Open(engine_lib, e == 0 ? cur_weights : cand_weights, batch, device)) {
+        if (err) snprintf(err, 256, "%s", h->err.c_str());
+        return 1;
+      }
+    }
+    nn[e].reset(new NNInterface(batch, NNInterface::kTimeoutUs, (size_t)cache_size, std::move(ev),
+                                NNInterface::SignalKind::kExplicit, num_games));
+  }
+  std::vector<EvalGameOutcome> outcomes(num_games);
+  std::vector<long> moves(num_games, 0), visits(num_games, 0), collisions(num_games, 0);
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> threads;
+  for (int g = 0; g < num_games; ++g)
+    threads.emplace_back([&, g] {   // PlayEvalGame, eval.cc:103-518
+      Probability prob(seed * 0x9E3779B97F4A7C15ull + (uint64_t)g * 0xBF58476D1CE4E5B9ull);
+      const bool cur_is_black = g % 2 == 0;
+      const int player_of[2] = {cur_is_black ? 0 : 1, cur_is_black ? 1 : 0};   // colour index (0 black) -> player
+      Game game(7.5f, true);
+      std::unique_ptr<BiasCache> bias[2];
+      NodePool pool[2];
+      TreeNode* tree[2];
+      std::unique_ptr<ThreadedSearch> search[2];
+      for (int s = 0; s < 2; ++s) {
+        const EvalPlayerConfig& c = pc[player_of[s]];
+        pool[s].set_graph(c.use_mcgs);
+        if (c.use_bias_cache) bias[s].reset(new BiasCache(c.bias_cache_alpha, c.bias_cache_lambda));
+        tree[s] = pool[s].GetOrCreate(game.board().hash(), kBlack, false);
+        search[s].reset(new ThreadedSearch(nn[player_of[s]]->MakeSlot(g * c.num_threads_per_game), bias[s].get()));
+      }
+      Color color = kBlack, resigned = kEmpty;
+      while (!game.IsGameOver() && game.num_moves() < max_moves) {
+        const int s = color == kBlack ? 0 : 1;
+        const EvalPlayerConfig& c = pc[player_of[s]];
+        ThreadedSearch::Params p;
+        p.num_threads = c.num_threads_per_game;
+        p.total_visit_budget = c.time_ms > 0 ? (1 << 30) : c.n;
+        p.total_visit_time_ms = c.time_ms;
+        p.puct.c_puct = c.c_puct;
+        p.puct.c_puct_visit_scaling = c.c_puct_visit_scaling;
+        p.puct.root_fpu = c.root_fpu;
+        p.puct.enable_var_scaling = c.var_scale_cpuct;
+        p.puct.var_scale_prior_visits = c.var_scale_prior_visits;
+        p.fns = VirtualFns{c.q_fn, c.n_fn, c.vl_delta};
+        p.descent = c.descent_policy;
+        p.collision = c.collision_policy;
+        p.detector = c.collision_detector;
+        p.max_collision_retries = c.max_collision_retries;
+        p.max_o_ratio = c.max_o_ratio;
+        const ThreadedSearch::Result r = search[s]->Run(prob, game, &pool[s], tree[s], color, p);
+        visits[g] += r.num_visits;
+        collisions[g] += r.num_collisions;
+        if (VOutcome(tree[s]) < kResignThreshold) { resigned = color; break; }   // eval.cc:277-282
+        game.PlayMove(r.move, color);
+        color = Opp(color);
+        for (int t = 0; t < 2; ++t) {   // both trees follow the move, eval.cc:318-352
+          TreeNode* next = tree[t]->child(MoveIdx(r.move));
+          if (!next) next = pool[t].GetOrCreate(game.board().hash(), color, game.IsGameOver());
+          pool[t].Reap(next);
+          tree[t] = next;
+          if (bias[t]) bias[t]->PruneUnused();
+        }
+      }
+      // a finished game leaves both interfaces' signalling quorum (eval.cc:505-507)
+      for (int s = 0; s < 2; ++s) nn[s]->MakeSlot(0).UnregisterSearchTask();
+      Color winner;
+      if (resigned != kEmpty) {
+        winner = Opp(resigned);
+      } else {
+        game.WriteResult();
+        winner = game.result().winner;
+      }
+      const int cur_result = winner == kEmpty ? 0 : ((winner == kBlack) == cur_is_black ? 1 : -1);
+      outcomes[g] = {cur_result, resigned != kEmpty, winner, EvalGameSgf(game, cur_is_black, resigned != kEmpty, winner)};
+      moves[g] = game.num_moves();
+    });
+  for (auto& t : threads) t.join();
+  if (out) {
+    std::memset(out, 0, sizeof *out);
+    FinishEvalMatch(outcomes, out);
+    for (int g = 0; g < num_games; ++g) { out->moves += moves[g]; out->visits += visits[g]; out->collisions += collisions[g]; }
+    out->batches = nn[0]->num_inferences() + nn[1]->num_inferences();
+    out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return 0;
+}
+
+// core::RelativeElo / the match summary, for the tests
+void p3host_match_summary(int num_cand_won, int num_games, float* out4) {
+  const MatchSummary m = SummarizeMatch(num_cand_won, num_games);
+  out4[0] = m.winrate; out4[1] = m.c95; out4[2] = m.rel_elo; out4[3] = m.elo_c95;
+}
+// parses a player config file; returns 0 and fills out[0..15] with its fields, or 1 with a message
+int p3host_parse_player_config(const char* path, float* out, char* err) {
+  EvalPlayerConfig c;
+  std::string e;
+  if (!ParsePlayerConfig(path, &c, &e)) { if (err) snprintf(err, 256, "%s", e.c_str()); return 1; }
+  const float v[16] = {(float)c.n, (float)c.num_threads_per_game, c.c_puct, c.c_puct_visit_scaling, c.root_fpu,
+                       (float)c.var_scale_cpuct, (float)(int)c.q_fn, (float)(int)c.n_fn, (float)(int)c.collision_policy,
+                       (float)(int)c.collision_detector, (float)(int)c.search_mode, (float)(int)c.descent_policy,
+                       c.max_o_ratio, (float)c.use_mcgs, (float)c.use_bias_cache, (float)c.time_ms};
+  std::memcpy(out, v, sizeof v);
   return 0;
 }
 

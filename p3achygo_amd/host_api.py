@@ -263,22 +263,64 @@ def sgf_from_moves(moves, komi: float = 7.5, write_result: bool = False, b_name:
 class EvalStats(C.Structure):
     _fields_ = [("games", C.c_int), ("cur_wins", C.c_int), ("cand_wins", C.c_int), ("draws", C.c_int),
                 ("resignations", C.c_int), ("moves", C.c_long), ("visits", C.c_long), ("collisions", C.c_long),
-                ("positions", C.c_long), ("batches", C.c_long), ("seconds", C.c_double)]
+                ("positions", C.c_long), ("batches", C.c_long), ("seconds", C.c_double), ("cache_hits", C.c_long),
+                ("winrate", C.c_float), ("c95", C.c_float), ("rel_elo", C.c_float), ("elo_c95", C.c_float)]
+
+
+def eval_set_search(mode: int = 0, q_fn: int = 2, n_fn: int = 1, collision: int = 0, detector: int = 0,
+                    descent: int = 0, max_o_ratio: float = 1.0, use_mcgs: bool = False, bias_lambda: float = 0.0,
+                    bias_alpha: float = 0.8, cache_entries_per_game: int = 256) -> None:
+    """Parallel-search knobs of subsequent eval matches (PlayerSearchConfig, player_config.h:60-108):
+    mode 0 concurrent / 1 batch; q_fn 0 identity / 1 virtual_loss / 2 virtual_loss_soft; n_fn 0
+    identity / 1 virtual_visit; collision 0 abort / 1 retry / 2 smart_retry; detector 0 noop / 1
+    n_in_flight / 2 level_saturation / 3 product; descent 0 deterministic / 1 bu_uct."""
+    L = lib()
+    L.p3host_eval_set_search.argtypes = [C.c_int] * 5
+    L.p3host_eval_set_search(mode, q_fn, n_fn, collision, detector)
+    L.p3host_eval_set_search_ex.argtypes = [C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int]
+    L.p3host_eval_set_search_ex(descent, max_o_ratio, int(use_mcgs), bias_lambda, bias_alpha, cache_entries_per_game)
+
+
+def eval_set_paths(cur_config: str = "", cand_config: str = "", recorder_dir: str = "", res_write_path: str = "") -> None:
+    """--cur_config / --cand_config / --recorder_path / --res_write_path of subsequent eval matches."""
+    L = lib()
+    L.p3host_eval_set_paths.argtypes = [C.c_char_p] * 4
+    L.p3host_eval_set_paths(cur_config.encode(), cand_config.encode(), recorder_dir.encode(), res_write_path.encode())
 
 
 def eval_match(cur_weights: str | None, cand_weights: str | None, num_games: int, visits_per_move: int = 128,
                leaves_per_round: int = 8, max_moves: int = 600, num_threads: int = 8, seed: int = 1,
-               device: int = 0) -> EvalStats:
-    """Model-vs-model games with the batch parallel search (cc/eval).  weights=None -> NullEvaluator."""
+               device: int = 0, engine_lib: str | None = None) -> EvalStats:
+    """Model-vs-model games with the batch parallel search (cc/eval), all games advanced together by
+    the batching scheduler.  weights=None -> NullEvaluator."""
     L = lib()
     L.p3host_eval_match.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_uint64, C.POINTER(EvalStats), C.c_char_p]
     st = EvalStats()
     err = C.create_string_buffer(256)
-    elib = os.path.join(_HERE, "csrc", "libp3hip.so").encode() if cur_weights else None
+    elib = (engine_lib or os.path.join(_HERE, "csrc", "libp3hip.so")).encode() if cur_weights else None
     rc = L.p3host_eval_match(elib, cur_weights.encode() if cur_weights else None,
                              cand_weights.encode() if cand_weights else None, device, num_games, visits_per_move,
                              leaves_per_round, max_moves, num_threads, seed, C.byref(st), err)
     if rc != 0:
         raise RuntimeError(f"eval_match rc={rc}: {err.value.decode()}")
+    return st
+
+
+def eval_match_threads(cur_weights: str | None, cand_weights: str | None, num_games: int, visits_per_move: int = 128,
+                       threads_per_game: int = 8, max_moves: int = 600, cache_size: int = 1 << 20, seed: int = 1,
+                       device: int = 0, engine_lib: str | None = None) -> EvalStats:
+    """The reference's own shape of the match (eval/main.cc:380-452): one thread per game, two
+    NNInterfaces (kExplicit signalling, NN cache on), the threaded mcts::Search per move."""
+    L = lib()
+    L.p3host_eval_match_threads.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_long, C.c_uint64, C.POINTER(EvalStats), C.c_char_p]
+    st = EvalStats()
+    err = C.create_string_buffer(256)
+    elib = (engine_lib or os.path.join(_HERE, "csrc", "libp3hip.so")).encode() if cur_weights else None
+    rc = L.p3host_eval_match_threads(elib, cur_weights.encode() if cur_weights else None,
+                                     cand_weights.encode() if cand_weights else None, device, num_games,
+                                     visits_per_move, threads_per_game, max_moves, cache_size, seed, C.byref(st), err)
+    if rc != 0:
+        raise RuntimeError(f"eval_match_threads rc={rc}: {err.value.decode()}")
     return st

@@ -9,6 +9,18 @@ import pytest
 from p3achygo_amd import host_api
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _ladder_throughput_mode(built):
+    """These tests exercise scheduling and search plumbing over the uniform NullEvaluator, whose
+    search trees wander into chaotic positions where the exact ladder read-out takes seconds
+    (millions of nodes): they run the host's opt-in ladder work bound.  Bit-exactness of the
+    default mode is pinned in tests/test_rules_cpu.py."""
+    from p3achygo_amd import host_api as _h
+    _h.set_ladder_budget(20000)
+    yield
+    _h.set_ladder_budget(0)
+
+
 @pytest.fixture(scope="module")
 def L(built):
     lib = host_api.lib()
@@ -119,3 +131,121 @@ def test_fruitless_rounds_end_the_search(L):
     complete; the search gives up instead of spinning (the reference would not terminate)."""
     o = run(L, 2, 5000, 0, 2, 1, 0, 1)
     assert 0 < o[0] < 5000 and o[5] >= 0 and o[8] == 0
+
+
+# ---- round 2: Elo, player configs, NN cache, SGF output, BuUct / graph search, threaded search ------
+
+def test_relative_elo_and_match_summary(L):
+    """core::RelativeElo (cc/core/elo.h) and the summary eval/main.cc:459-471 prints."""
+    out = np.zeros(4, np.float32)
+    L.p3host_match_summary.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    L.p3host_match_summary(60, 100, out.ctypes.data)
+    wr = 0.6
+    c95 = 1.96 * np.sqrt(wr * (1 - wr) / 100)
+    assert out[0] == pytest.approx(wr) and out[1] == pytest.approx(c95, rel=1e-6)
+    assert out[2] == pytest.approx(400 * np.log10(wr / (1 - wr)), rel=1e-6)          # +70.4 Elo
+    assert out[3] == pytest.approx(400 * np.log10((.5 + c95) / (.5 - c95)), rel=1e-5)
+    L.p3host_match_summary(50, 100, out.ctypes.data)
+    assert out[2] == 0.0
+
+
+def test_player_config_file(L, tmp_path):
+    """ParsePlayerConfigFile (player_config.h:133-260): key: value lines, comments, enums by name;
+    an unknown key is an error."""
+    L.p3host_parse_player_config.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p]
+    p = tmp_path / "cand.cfg"
+    p.write_text("# candidate\nn: 200\nnum_threads_per_game: 16\nc_puct: 1.25\n\nq_fn: virtual_loss\nn_fn: identity\n"
+                 "collision_policy: smart_retry\ncollision_detector: product\nsearch_mode: batch\n"
+                 "descent_policy: bu_uct\nmax_o_ratio: 0.7\nuse_mcgs: true\nuse_bias_cache: 1\ntime_ms: 250\n")
+    out = np.zeros(16, np.float32)
+    err = C.create_string_buffer(256)
+    assert L.p3host_parse_player_config(str(p).encode(), out.ctypes.data, err) == 0, err.value
+    assert list(out[:2]) == [200, 16] and out[2] == pytest.approx(1.25)
+    assert list(out[6:12]) == [1, 0, 2, 3, 1, 1] and out[12] == pytest.approx(0.7)
+    assert list(out[13:16]) == [1, 1, 250]
+    p.write_text("n: 10\nno_such_key: 1\n")
+    assert L.p3host_parse_player_config(str(p).encode(), out.ctypes.data, err) == 1
+    assert b"no_such_key" in err.value
+
+
+def test_eval_match_cache_sgf_and_result_file(built, tmp_path):
+    """The scheduler-driven match with the per-game NN cache on, SGF recording and the result file
+    (eval/main.cc: --cache_size, --recorder_path, --res_write_path): cached positions cost no engine
+    slot, one SGF line per game with the players' names by colour, relative Elo written as %f."""
+    rec, res = tmp_path / "rec", tmp_path / "elo.txt"
+    try:
+        host_api.eval_set_search(cache_entries_per_game=512)
+        host_api.eval_set_paths(recorder_dir=str(rec), res_write_path=str(res))
+        st = host_api.eval_match(None, None, num_games=6, visits_per_move=16, leaves_per_round=4, max_moves=24,
+                                 num_threads=2, seed=3)
+        host_api.eval_set_search(cache_entries_per_game=0)
+        host_api.eval_set_paths()
+        st0 = host_api.eval_match(None, None, num_games=6, visits_per_move=16, leaves_per_round=4, max_moves=24,
+                                  num_threads=2, seed=3)
+    finally:
+        host_api.eval_set_search()
+        host_api.eval_set_paths()
+    assert st.games == 6 and st.moves == 6 * 24
+    # with tree reuse and five last moves in the key (NNKey, nn_interface.h:206-228) a repeat needs the
+    # same recent history, so hits are rare; what must hold is the accounting: same searches, and
+    # every cached evaluation is one engine slot less
+    assert st.cache_hits >= 0 and st0.cache_hits == 0
+    assert st.positions + st.cache_hits == st0.positions
+    assert st.winrate == pytest.approx(st.cand_wins / 6)
+    files = sorted((rec / "sgf").iterdir())
+    assert [f.name for f in files] == ["gen000_b000_g006_EVAL_cur_cand.done", "gen000_b000_g006_EVAL_cur_cand.sgf"]
+    lines = files[1].read_text().splitlines()
+    assert len(lines) == 6 and all(l.startswith("(;FF[4]GM[1]KM[7.5]RE[") for l in lines)
+    assert "PB[cur]PW[cand]" in lines[0] and "PB[cand]PW[cur]" in lines[1]      # cur is Black in even games
+    assert lines[0].count(";B[") + lines[0].count(";W[") == 24
+    assert float(res.read_text()) == pytest.approx(st.rel_elo, abs=1e-4) or not np.isfinite(st.rel_elo)
+
+
+@pytest.mark.parametrize("mcgs,descent,bias", [(True, 0, 0.0), (False, 1, 0.0), (True, 1, 0.3)])
+def test_eval_match_graph_search_buuct_and_bias_cache(built, mcgs, descent, bias):
+    """use_mcgs (McgsNodeTable, node_table.h:77-118), descent_policy bu_uct (search.h:174-251) and
+    use_bias_cache on the eval path: the matches finish with consistent counts."""
+    try:
+        host_api.eval_set_search(descent=descent, max_o_ratio=0.8, use_mcgs=mcgs, bias_lambda=bias)
+        st = host_api.eval_match(None, None, num_games=4, visits_per_move=24, leaves_per_round=4, max_moves=20,
+                                 num_threads=2, seed=5)
+    finally:
+        host_api.eval_set_search()
+    assert st.games == 4 and st.moves == 4 * 20 and st.cur_wins + st.cand_wins + st.draws == 4
+    assert st.visits >= 24 * st.moves
+
+
+THREADED = [
+    # threads, budget, q_fn, n_fn, collision, detector, descent, graph, time_ms
+    (8, 64, 2, 1, 0, 0, 0, 0, 0),      # the defaults of player_config.h
+    (8, 64, 1, 1, 2, 1, 0, 0, 0),      # hard virtual loss, smart retry, n-in-flight detector
+    (4, 48, 0, 1, 1, 3, 0, 0, 0),      # search_test.cc MakeParams + retry + product detector
+    (8, 64, 2, 1, 0, 0, 1, 0, 0),      # BuUct descent
+    (8, 64, 2, 1, 0, 0, 0, 1, 0),      # graph search (McgsNodeTable)
+    (6, 0, 2, 1, 0, 0, 1, 1, 40),      # time control instead of a visit budget
+]
+
+
+@pytest.mark.parametrize("cfg", THREADED)
+def test_threaded_concurrent_search(L, cfg):
+    """mcts::Search in Mode::kConcurrent as the reference runs it (threaded_search.h: worker threads,
+    node locks, two barriers per round, async NNInterface slot with kExplicit signalling, bias
+    cache on): six searches of a game with tree reuse; after every one nothing is left in flight,
+    n = 1 + sum(child visits) on every inner node, the visit count is in [budget, budget +
+    threads) (search_test.cc:130-222) and the move is legal."""
+    L.p3host_test_threaded_search.argtypes = [C.c_int] * 10 + [C.c_uint64, C.c_void_p]
+    st = (C.c_long * 5)()
+    mask = L.p3host_test_threaded_search(*cfg, 6, 7, st)
+    assert mask == 0, f"invariant mask {mask:#x}"
+    assert st[4] == 6 and st[0] >= (6 * cfg[1] if cfg[8] == 0 else 6)
+    assert st[1] <= st[2] + 6 * cfg[0]                         # aborts come from collisions
+
+
+def test_eval_match_thread_per_game_with_two_nn_interfaces(built):
+    """eval/main.cc:380-452 as written there: a thread per game, each player's engine behind its own
+    kExplicit NNInterface (num_shared_search_tasks = games, NN cache on), the threaded search per
+    move with slot range [game * T, (game + 1) * T)."""
+    st = host_api.eval_match_threads(None, None, num_games=4, visits_per_move=24, threads_per_game=4, max_moves=16,
+                                     cache_size=1 << 14, seed=2)
+    assert st.games == 4 and st.cur_wins + st.cand_wins + st.draws == 4 and st.moves == 4 * 16
+    assert st.visits >= 24 * st.moves and st.batches > 0

@@ -6,6 +6,19 @@ import numpy as np
 import pytest
 
 
+
+@pytest.fixture(autouse=True, scope="module")
+def _ladder_throughput_mode(built):
+    """These tests exercise scheduling and search plumbing over the uniform NullEvaluator, whose
+    search trees wander into chaotic positions where the exact ladder read-out takes seconds
+    (millions of nodes): they run the host's opt-in ladder work bound.  Bit-exactness of the
+    default mode is pinned in tests/test_rules_cpu.py."""
+    from p3achygo_amd import host_api as _h
+    _h.set_ladder_budget(20000)
+    yield
+    _h.set_ladder_budget(0)
+
+
 @pytest.fixture(scope="module")
 def host(built):
     from p3achygo_amd import host_api

@@ -79,7 +79,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // kernel column kx, the odd 16-row tile and the k32 index inside the tap are immediates.
 // Body = one kernel row (KW taps), runtime loop over ky.
 template <class G, int COUT_PASS, int KW, int NTAPS_PAD, int NTn = 0>
-__device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS)>& ring, char* smem,
+__device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS, G::KMS), G::NW>& ring, char* smem,
                                                f32x4 (&acc)[4][NTn]) {
   using T = Tiling16<G, COUT_PASS>;
   static_assert(NTn == T::NT, "accumulator shape");
@@ -88,7 +88,8 @@ __device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS)>&
   constexpr int NQ = G::CB / 32;                   // k32-steps per tap
   constexpr int U = KW * NQ;                       // unrolled body: one kernel row
   constexpr int NOUT = KW;
-  static_assert(U % 2 == 0, "segment shape");
+  constexpr int KM32 = G::KMS / 2;                 // k32 steps per ring macro-step (2, or 1 in the 4-wave kernel)
+  static_assert(U % 2 == 0 && U % KM32 == 0 && (KM32 == 1 || KM32 == 2), "segment shape");
   constexpr int KB = COUT_PASS * 32;               // bytes per k16 block of the weight panel
   const int lane = launder(threadIdx.x & 63);
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -105,7 +106,7 @@ __device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS)>&
   auto fetch_piece = [&](int o, auto V, auto J) {
     constexpr int v = decltype(V)::value, j = decltype(J)::value;
     constexpr int vv = v % U;
-    constexpr int kk = vv % 2;                     // k32 index inside the ring macro-step
+    constexpr int kk = vv % KM32;                  // k32 index inside the ring macro-step
     constexpr int q32 = vv % NQ;                   // k32 index inside the tap
     constexpr int kx = vv / NQ;
     constexpr int nxt = v % 2;                     // U is even: parity of the global step

@@ -38,15 +38,19 @@ constexpr int kBL = 19;
 constexpr int kKMS = 4;           // k16-steps (K = 64) per ring macro-step
 constexpr int kRingSlots = 3;     // R
 constexpr int kRingDepth = 2;     // D = R - 1 (see ring_acquire)
-// bytes of one macro-step for a COUT_PASS-wide weight panel: kKMS blocks of [2][CP][8] fp16
-constexpr int ring_slot_bytes(int cout_pass) { return kKMS * cout_pass * 32; }
-constexpr int ring_bytes(int cout_pass) { return kRingSlots * ring_slot_bytes(cout_pass); }
+// bytes of one macro-step for a COUT_PASS-wide weight panel: `kms` blocks of [2][CP][8] fp16
+constexpr int ring_slot_bytes(int cout_pass, int kms = kKMS) { return kms * cout_pass * 32; }
+constexpr int ring_bytes(int cout_pass, int kms = kKMS) { return kRingSlots * ring_slot_bytes(cout_pass, kms); }
 
 // ---------------------------------------------------------------------------------------
 // Geometry of one conv "space": NPOS positions, NT_TOTAL 32-wide location tiles each.
-template <int NPOS_, int CB_, int KW_>
+// NW = waves per workgroup (8; 4 for the two-workgroups-per-CU form of the C = 128 block kernel),
+// KMS = k16 steps per ring macro-step.
+template <int NPOS_, int CB_, int KW_, int NW_ = 8, int KMS_ = kKMS>
 struct Geo {
   static constexpr int NPOS = NPOS_;
+  static constexpr int NW = NW_;
+  static constexpr int KMS = KMS_;
   static constexpr int CB = CB_;                 // channels resident in the act buffer
   static constexpr int NCH = CB / 8;             // 16-byte chunks per slot
   // bytes per slot: the channels plus one 16-byte pad.  The slot stride is then an odd
@@ -112,12 +116,14 @@ __device__ __forceinline__ h4 bn_mish4(f32x4 v, f32x4 sc, f32x4 sh) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Weight ring.  RS = bytes per macro-step (16 KiB for 128-wide panels, 8 KiB for 64-wide);
-// each of the 8 waves copies RS/8 bytes (G = RS/8192 glds of 1 KiB) per macro-step.
-template <int RS>
+// Weight ring.  RS = bytes per macro-step (16 KiB for 128-wide panels, 8 KiB for 64-wide, 4 KiB
+// for the 4-wave kernel's K = 32 steps); each of the NW waves copies RS/NW bytes (G = RS/NW/1024
+// glds of 1 KiB) per macro-step.
+template <int RS, int NW = 8>
 struct Ring {
-  static constexpr int G = RS / 8192;
-  static_assert(G == 1 || G == 2, "ring slot size");
+  static constexpr int G = RS / (NW * 1024);
+  static constexpr int PIECE = RS / NW;
+  static_assert((G == 1 || G == 2) && G * NW * 1024 == RS, "ring slot size");
   // Scalar state only, kept as running pointers and rotating slot addresses so that one
   // acquire costs a handful of SALU instructions (an index-based ring recomputed two 64-bit
   // stream addresses, three LDS addresses and three wrap-arounds per acquire: ~100 scalar
@@ -145,13 +151,13 @@ __device__ __forceinline__ void rotate_left(uint32_t (&v)[N]) {
   v[N - 1] = t;
 }
 
-template <int RS>
-__device__ __forceinline__ void ring_issue(Ring<RS>& r, char* smem) {
+template <int RS, int NW>
+__device__ __forceinline__ void ring_issue(Ring<RS, NW>& r, char* smem) {
   const uint32_t lane16 = (threadIdx.x & 63) * 16;
   const char* gp = r.gcur + lane16;      // uniform base + 32-bit lane offset
   char* lp = smem + r.fill[0];
 #pragma unroll
-  for (int i = 0; i < Ring<RS>::G; ++i)
+  for (int i = 0; i < Ring<RS, NW>::G; ++i)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + i * 1024),
                                      (__attribute__((address_space(3))) void*)(lp + i * 1024), 16, 0, 0);
   r.gcur += RS;
@@ -159,30 +165,22 @@ __device__ __forceinline__ void ring_issue(Ring<RS>& r, char* smem) {
   rotate_left(r.fill);
 }
 
-template <int RS>
-__device__ __forceinline__ void ring_init(Ring<RS>& r, char* smem, const void* gbase,
+template <int RS, int NW>
+__device__ __forceinline__ void ring_init(Ring<RS, NW>& r, char* smem, const void* gbase,
                                           int nms_total, uint32_t lds_base) {
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  r.gbeg = (const char*)gbase + wid * (RS / 8);
+  r.gbeg = (const char*)gbase + wid * (RS / NW);
   r.gend = r.gbeg + (size_t)nms_total * RS;
   r.gcur = r.gbeg;
   r.lds_base = lds_base;
 #pragma unroll
   for (int i = 0; i < kRingSlots; ++i) {
     r.use[i] = lds_base + i * RS;
-    r.fill[i] = lds_base + i * RS + wid * (RS / 8);
+    r.fill[i] = lds_base + i * RS + wid * (RS / NW);
   }
   r.tol = 0;
   r.extra = 0;
   for (int i = 0; i < kRingDepth; ++i) ring_issue(r, smem);
-}
-
-// The next wrap of the prefetch pointer goes to the start of another stream (the caller sets
-// gend once the wrap has happened).
-template <int RS>
-__device__ __forceinline__ void ring_retarget(Ring<RS>& r, const void* gbase) {
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  r.gbeg = (const char*)gbase + wid * (RS / 8);
 }
 
 // Makes the next macro-step readable and returns its LDS byte offset.
@@ -202,10 +200,10 @@ __device__ __forceinline__ void ring_retarget(Ring<RS>& r, const void* gbase) {
 // the first acquire of a segment (it doubles as the "previous layer written" barrier); a
 // K loop that knows how many reads it issued after the last fragment read of the macro-step
 // being recycled passes that count instead and does not stall on its own recent reads.
-template <int LGKM = 0, int RS = 0>
-__device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
+template <int LGKM = 0, int RS = 0, int NW = 8>
+__device__ __forceinline__ uint32_t ring_acquire(Ring<RS, NW>& r, char* smem) {
   static_assert(kRingDepth == 2 && kXLoads == 12, "vmcnt immediates below");
-  constexpr int G = Ring<RS>::G;  // base immediate (D-1)*G = G
+  constexpr int G = Ring<RS, NW>::G;  // base immediate (D-1)*G = G
   if (r.tol > 0) {
     r.tol--;
     if (r.extra == 12) {
@@ -236,13 +234,13 @@ __device__ __forceinline__ uint32_t ring_acquire(Ring<RS>& r, char* smem) {
 // Call right after issuing `extra` (12, 24, 36 or 48) ordinary vector-memory operations whose
 // completion should not be forced by the next D ring acquires (and nothing else since the
 // last ring_issue): the glds those acquires wait for are older than all of them.
-template <int RS>
-__device__ __forceinline__ void ring_note_inflight(Ring<RS>& r, int extra) {
+template <int RS, int NW>
+__device__ __forceinline__ void ring_note_inflight(Ring<RS, NW>& r, int extra) {
   r.tol = kRingDepth;
   r.extra = extra;
 }
-template <int RS>
-__device__ __forceinline__ void ring_note_xloads(Ring<RS>& r) { ring_note_inflight(r, kXLoads); }
+template <int RS, int NW>
+__device__ __forceinline__ void ring_note_xloads(Ring<RS, NW>& r) { ring_note_inflight(r, kXLoads); }
 
 __device__ __forceinline__ void ring_drain() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -260,12 +258,12 @@ __device__ __forceinline__ void lds_barrier() {
 template <class G, int COUT_PASS>
 struct Tiling {
   static constexpr int CG = COUT_PASS / 64;
-  static constexpr int LG = 8 / CG;
+  static constexpr int LG = G::NW / CG;
   static constexpr int MT = 2;
   static constexpr int NT = (G::NT_TOTAL + LG - 1) / LG;
-  static constexpr int KMS = kKMS;                  // k16-steps per macro-step
-  static constexpr int RS = ring_slot_bytes(COUT_PASS);
-  static_assert(CG * LG == 8 && (CG == 1 || CG == 2), "tiling");
+  static constexpr int KMS = G::KMS;                // k16-steps per macro-step
+  static constexpr int RS = ring_slot_bytes(COUT_PASS, G::KMS);
+  static_assert(CG * LG == G::NW && (CG == 1 || CG == 2), "tiling");
 };
 
 // slot index of row 0 of location tile t
@@ -319,7 +317,7 @@ __device__ __forceinline__ void wait_lgkm_n(int n) {
 // SWAP: issue mfma(act fragment, weight fragment) instead, i.e. D[act row][weight row]: a lane
 // then holds 4 consecutive ACT rows for one weight row (k_bdense: rows are channels).
 template <class G, int COUT_PASS, int KW, int NTAPS_PAD, bool SWAP = false, int NTn = 0>
-__device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS)>& ring, char* smem,
+__device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS, G::KMS), G::NW>& ring, char* smem,
                                              f32x16 (&acc)[2][NTn]) {
   using T = Tiling<G, COUT_PASS>;
   static_assert(NTn == T::NT, "accumulator shape");
@@ -648,7 +646,7 @@ __device__ __forceinline__ void stage_in(char* smem, const _Float16* __restrict_
 
 template <class G>
 __device__ __forceinline__ void act_zero(char* smem) {
-  for (int i = threadIdx.x * 16; i < G::ACT_BYTES; i += kWG * 16) *(f32x4*)(smem + i) = f32x4{0, 0, 0, 0};
+  for (int i = threadIdx.x * 16; i < G::ACT_BYTES; i += G::NW * 64 * 16) *(f32x4*)(smem + i) = f32x4{0, 0, 0, 0};
 }
 
 // Epilogue B: out[c][loc] = acc + residual (read from the same place) -> fp16 global, in

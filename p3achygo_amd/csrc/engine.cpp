@@ -163,6 +163,7 @@ struct BlockPlan {
   std::vector<LayerPlan> layers;
   size_t stream_off = 0;
   int nms = 0;
+  size_t stream_bytes = 0;   // fused blocks: the launch picks the macro-step size (kernels.h block_macro_step_bytes)
   FoldedBN bn[p3::kMaxBlockLayers];
   // broadcast extras
   size_t stream2_off = 0, stream3_off = 0;
@@ -178,6 +179,7 @@ struct p3hip_engine {
   uint32_t flags = 0;
   WeightFile wf;
   int n_cu = 256;
+  bool c128_wg8 = false;   // P3HIP_C128_WG8: C = 128 blocks as one 8-wave workgroup per CU (A/B timing)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // p3hip_time_trunk_kernel: event pairs around every fused-block launch of a forward pass
@@ -280,6 +282,7 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
     for (auto& rs : run_streams) {
       BlockPlan& b = e->blocks[rs.first];
       b.stream_off = add_stream(ar, rs.second, b.nms, Cb);
+      b.stream_bytes = rs.second.size() * 2;
     }
     run_streams.clear();
   };
@@ -432,9 +435,10 @@ p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
   a.nblk = count;
   // the streams of consecutive fused blocks lie back to back in the arena (build_plan)
   a.wstream = e->d_arena + e->blocks[first].stream_off;
+  const size_t ms_bytes = (size_t)p3::block_macro_step_bytes(e->wf.C, e->c128_wg8);
   for (int b = 0; b < count; ++b) {
     const BlockPlan& bp = e->blocks[first + b];
-    a.nms_total += bp.nms;
+    a.nms_total += (int)(bp.stream_bytes / ms_bytes);
     for (int j = 0; j < p3::kMaxBlockLayers; ++j) {
       a.blk[b].scale[j] = e->dev<float>(bp.bn[j].scale_off);
       a.blk[b].shift[j] = e->dev<float>(bp.bn[j].shift_off);
@@ -503,7 +507,7 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
       p3::BlockArgs a = block_args(e, bi, run, npos);
       const bool timed = e->time_blocks && 2 * e->timed_blocks + 1 < (int)e->blk_ev.size();
       if (timed) hipEventRecord(e->blk_ev[2 * e->timed_blocks], s);
-      if (!e->check(p3::launch_block(C, bp.kind, wf.inner, a, grid_for(e, npos, npw), s), "launch k_block")) return false;
+      if (!e->check(p3::launch_block(C, bp.kind, wf.inner, e->c128_wg8, a, e->n_cu, s), "launch k_block")) return false;
       if (timed) hipEventRecord(e->blk_ev[2 * e->timed_blocks++ + 1], s);
       bi += run - 1;
     }
@@ -550,6 +554,7 @@ p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version
   e->batch = batch_size;
   e->device = device_ordinal;
   e->flags = flags;
+  e->c128_wg8 = getenv("P3HIP_C128_WG8") != nullptr;
   auto fail = [&](const std::string& m) {
     g_create_error = m;
     p3hip_destroy(e);

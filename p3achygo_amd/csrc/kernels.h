@@ -109,7 +109,9 @@ struct HeadsArgs {
   const float *score_out_w, *score_out_b;  // [V], [1]
 };
 
-hipError_t launch_block(int C, int kind, int L, const BlockArgs& a, int grid, hipStream_t s);
+// picks its own grid (one workgroup per CU, or two 4-wave workgroups per CU at C = 128 unless wg8)
+hipError_t launch_block(int C, int kind, int L, bool wg8, const BlockArgs& a, int n_cu, hipStream_t s);
+int block_macro_step_bytes(int C, bool wg8);
 hipError_t launch_init(int C, const InitArgs& a, int grid, hipStream_t s);
 // which: 0 = broadcast conv_first (bn+mish prologue, mish epilogue), 1 = broadcast
 // conv_last (+residual), 2 = head convs (fp32 out, COUT = 96)

@@ -39,10 +39,16 @@ namespace p3 {
 // The values are the ones the block-major order produced: bn0 + mish is applied to the fp16
 // value that is stored, exactly what a re-load would return (bit-identical to one launch per
 // block, tests/test_engine_gpu.py::test_fused_block_launches_equal_one_launch_per_block).
-template <int C, int CB, int KIND, int L>
-__global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
-  constexpr int NPOS = 128 / CB;
-  using G = Geo<NPOS, CB, 3>;
+//
+// NW = 8: one 512-thread workgroup per CU (C = 256: one position; C = 128: two positions side by
+// side in the act buffer).  NW = 4 (C = 128 only): a 256-thread workgroup per position with
+// K = 32 ring steps — 60.6 KB of activations + 12 KB of ring, so TWO workgroups share a CU and one
+// workgroup's BN + mish / store phases run under the other's MFMA phases.
+template <int C, int CB, int KIND, int L, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
+  static_assert(NW == 8 || (NW == 4 && CB == 64), "4-wave workgroups: one 64-channel position each");
+  constexpr int NPOS = NW == 8 ? 128 / CB : 1;
+  using G = Geo<NPOS, CB, 3, NW, NW == 8 ? kKMS : 2>;
   using T = Tiling16<G, CB>;
   constexpr int NT = T::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -50,7 +56,7 @@ __global__ void __launch_bounds__(kWG, 2) k_block(BlockArgs a) {
   static_assert(C / CB == 2, "two input slices / two output passes");
 
   act_zero<G>(smem);
-  Ring<T::RS> ring;
+  Ring<T::RS, NW> ring;
   ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
   lds_barrier();
 
@@ -461,6 +467,7 @@ constexpr int kTtStride = 784;  // bytes per channel row in LDS: 384 fp16 + 16 B
 
 // Tt seen as a conv act buffer: one slot per channel (128 per pass), K = 384 board points.
 struct GeoTt {
+  static constexpr int NW = 8, KMS = kKMS;
   static constexpr int NPOS = 1, CB = 384, NCH = 48, SLOTB = kTtStride, PAD = 0, S = 1, NROWS = 128,
                        NT_POS = 4, PADTOP = 0, PSLOTS = 128, ACT_BYTES = 128 * kTtStride, NT_TOTAL = 4;
 };
@@ -882,30 +889,41 @@ __global__ void __launch_bounds__(1024) k_heads(HeadsArgs a) {
 // =======================================================================================
 // Host-side launchers
 // =======================================================================================
-template <int C, int CB, int KIND, int L>
-static hipError_t launch_block_t(const BlockArgs& a, int grid, hipStream_t s) {
-  using G = Geo<128 / CB, CB, 3>;
-  constexpr size_t lds = G::ACT_BYTES + ring_bytes(CB);
+template <int C, int CB, int KIND, int L, int NW>
+static hipError_t launch_block_t(const BlockArgs& a, int n_cu, hipStream_t s) {
+  constexpr int NPOS = NW == 8 ? 128 / CB : 1;
+  using G = Geo<NPOS, CB, 3, NW, NW == 8 ? kKMS : 2>;
+  constexpr size_t lds = G::ACT_BYTES + ring_bytes(CB, G::KMS);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_block<C, CB, KIND, L>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_block<C, CB, KIND, L, NW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_block<C, CB, KIND, L>), dim3(grid), dim3(kWG), lds, s, a);
+  const int groups = (a.npos + NPOS - 1) / NPOS, cap = NW == 8 ? n_cu : 2 * n_cu;   // NW = 4: two workgroups per CU
+  hipLaunchKernelGGL((k_block<C, CB, KIND, L, NW>), dim3(groups < cap ? groups : cap), dim3(NW * 64), lds, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_block(int C, int kind, int L, const BlockArgs& a, int grid, hipStream_t s) {
-  if (C == 256 && kind == 0 && L == 3) return launch_block_t<256, 128, 0, 3>(a, grid, s);
-  if (C == 256 && kind == 0 && L == 2) return launch_block_t<256, 128, 0, 2>(a, grid, s);
-  if (C == 256 && kind == 0 && L == 1) return launch_block_t<256, 128, 0, 1>(a, grid, s);
-  if (C == 256 && kind == 1) return launch_block_t<256, 128, 1, 2>(a, grid, s);
-  if (C == 128 && kind == 0 && L == 3) return launch_block_t<128, 64, 0, 3>(a, grid, s);
-  if (C == 128 && kind == 0 && L == 2) return launch_block_t<128, 64, 0, 2>(a, grid, s);
-  if (C == 128 && kind == 0 && L == 1) return launch_block_t<128, 64, 0, 1>(a, grid, s);
-  if (C == 128 && kind == 1) return launch_block_t<128, 64, 1, 2>(a, grid, s);
+// bytes of one ring macro-step of the block kernel that launch_block picks for width C
+int block_macro_step_bytes(int C, bool wg8) { return C == 256 ? 128 * 32 * kKMS : (wg8 ? 64 * 32 * kKMS : 64 * 32 * 2); }
+
+hipError_t launch_block(int C, int kind, int L, bool wg8, const BlockArgs& a, int n_cu, hipStream_t s) {
+  if (C == 256 && kind == 0 && L == 3) return launch_block_t<256, 128, 0, 3, 8>(a, n_cu, s);
+  if (C == 256 && kind == 0 && L == 2) return launch_block_t<256, 128, 0, 2, 8>(a, n_cu, s);
+  if (C == 256 && kind == 0 && L == 1) return launch_block_t<256, 128, 0, 1, 8>(a, n_cu, s);
+  if (C == 256 && kind == 1) return launch_block_t<256, 128, 1, 2, 8>(a, n_cu, s);
+  if (C == 128 && wg8) {   // P3HIP_C128_WG8: the one-workgroup-per-CU form, kept for A/B timing
+    if (kind == 0 && L == 3) return launch_block_t<128, 64, 0, 3, 8>(a, n_cu, s);
+    if (kind == 0 && L == 2) return launch_block_t<128, 64, 0, 2, 8>(a, n_cu, s);
+    if (kind == 0 && L == 1) return launch_block_t<128, 64, 0, 1, 8>(a, n_cu, s);
+    if (kind == 1) return launch_block_t<128, 64, 1, 2, 8>(a, n_cu, s);
+  }
+  if (C == 128 && kind == 0 && L == 3) return launch_block_t<128, 64, 0, 3, 4>(a, n_cu, s);
+  if (C == 128 && kind == 0 && L == 2) return launch_block_t<128, 64, 0, 2, 4>(a, n_cu, s);
+  if (C == 128 && kind == 0 && L == 1) return launch_block_t<128, 64, 0, 1, 4>(a, n_cu, s);
+  if (C == 128 && kind == 1) return launch_block_t<128, 64, 1, 2, 4>(a, n_cu, s);
   return hipErrorInvalidValue;
 }
 

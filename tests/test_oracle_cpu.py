@@ -246,3 +246,26 @@ def test_bad_weight_files_fail_creation_with_a_message(built, weight_files, tmp_
     p3.write_bytes(bytes(blob))
     with pytest.raises(engine.EngineError, match=r"policy\.conv_p\.w \(wrong size\)"):
         engine.HipEngine(str(p3), 4)
+
+
+@pytest.mark.parametrize("name", ["b12c256btl3", "b8c128nbt", "b15c192_classic"])
+def test_keras_name_map_covers_every_tensor(name):
+    """Keras layer/variable paths (python/model.py `name=` arguments) -> .p3w tensor names: one row
+    per tensor of the architecture, no duplicates on either side, and the renaming of a synthetic
+    checkpoint (arrays of the Keras shapes under the Keras paths) reproduces the .p3w tensors.  A
+    real `.keras` archive cannot be read here (no h5py / Keras): the map is the deliverable."""
+    from p3achygo_amd import keras_map, netspec
+    cfg = netspec.CONFIGS[name]
+    rows = keras_map.name_map(cfg)
+    specs = netspec.tensor_specs(cfg)
+    assert len(rows) == len(specs) == len({k for k, _ in rows}) == len({p for _, p in rows})
+    assert {p for _, p in rows} == {n for n, _, _ in specs}
+    W = netspec.generate_weights(cfg, randomize=True)
+    back = {p: k for k, p in rows}
+    ckpt = {back[n]: W[n] for n in W}
+    out = keras_map.rename(cfg, ckpt)
+    assert all(np.array_equal(out[n], W[n]) for n in W)
+    assert ("bottleneck_res_0/res_id_inner_1/conv/kernel", "blocks.0.conv2.w") in rows or cfg.block_type != "btl"
+    ckpt.pop(next(iter(ckpt)))
+    with pytest.raises(KeyError):
+        keras_map.rename(cfg, ckpt)

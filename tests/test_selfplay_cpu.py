@@ -371,3 +371,28 @@ def test_selfplay_host_over_the_cpu_engine_and_step_limit(built, weight_files):
     assert 0 < st.positions <= 6 * 8                 # at most one full batch of 8 games per step
     assert st.positions >= 6 * 8 - 16                # terminal / cached leaves leave a few slots empty
     assert st.seconds > 0
+
+
+def test_baseline_config_c1_plumbing_on_the_cpu_engine(built, weight_files):
+    """BASELINE configs[0]: "v4-b8 random-init net, 1 self-play thread, n=8 k=4 Gumbel, TF-CPU inference
+    (plumbing, no GPU)".  v4 = b8c128nbt with bias_cache_lambda 0.3 / alpha 0.8 (config/v4.json); the
+    reference's TF-CPU engine does not build, its stand-in is the CPU fp32
+    oracle behind the same C ABI.  One game thread, the first moves of a game (a full-size fp32 forward
+    pass takes 0.2 s on one core): every move costs at most n = 8 leaf evaluations plus its root.
+    Reproducibility of whole games is pinned on the tiny net (tests/test_bias_cache_cpu.py) and on
+    the GPU engine (tests/test_engine_gpu.py::test_config_c1_game_with_bias_cache_on_hip_engine)."""
+    import os
+    from conftest import ROOT
+    from p3achygo_amd import host_api
+    lib = os.path.join(ROOT, "oracle", "libp3cpu_engine.so")
+    os.environ["P3CPU_THREADS"] = "1"
+    host_api.set_ladder_budget(0)                        # reference-exact features
+    try:
+        host_api.set_bias_cache(0.3, 0.8)
+        w = weight_files("b8c128nbt")
+        mv, b, wsc, ev = host_api.selfplay_one_game(w, 8, 4, 6, seed=21, engine_lib=lib)
+    finally:
+        host_api.set_bias_cache(0.0, 0.8)
+        host_api.set_ladder_budget(20000)
+    assert len(mv) == 6 and len(set(int(m) for m in mv)) == 6 and all(m != 0 for m in mv)
+    assert 6 <= ev <= 6 * 9                              # root + at most n leaves per move

@@ -20,6 +20,7 @@
 // against it.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <functional>
 #include <atomic>
 #include <chrono>
@@ -506,6 +507,9 @@ class GameRunner {
 };
 
 // ---- scheduler -----------------------------------------------------------------------------
+// A pool of host threads that runs several ParallelFor jobs at once: every game group submits its
+// own job from its own driver thread, the workers always take the oldest job that still has
+// items, so a game that is slow to advance (a long ladder read-out) holds up its own group only.
 class WorkerPool {
  public:
   explicit WorkerPool(int n) {
@@ -519,66 +523,70 @@ class WorkerPool {
     cv_.notify_all();
     for (auto& t : threads_) t.join();
   }
-  // runs fn(i) for i in [0, n) on the pool and returns when all are done
+  // runs fn(i) for i in [0, n) on the pool and returns when all are done; callable from several
+  // threads at the same time
   template <class F>
   void ParallelFor(int n, F&& fn) {
-    std::function<void(int)> f = fn;
+    if (n <= 0) return;
+    Job job;
+    job.fn = fn;
+    job.total = n;
+    job.unfinished = n;
     {
       std::lock_guard<std::mutex> l(mu_);
-      job_ = &f;
-      next_.store(0);
-      total_ = n;
-      pending_ = (int)threads_.size();
-      ++gen_;
+      jobs_.push_back(&job);
     }
     cv_.notify_all();
     std::unique_lock<std::mutex> l(mu_);
-    done_cv_.wait(l, [this] { return pending_ == 0; });
-    job_ = nullptr;
+    job.done_cv.wait(l, [&] { return job.unfinished == 0; });
   }
 
  private:
+  struct Job {
+    std::function<void(int)> fn;
+    int total = 0, next = 0, unfinished = 0;   // guarded by mu_
+    std::condition_variable done_cv;
+  };
   void Loop() {
-    uint64_t seen = 0;
+    std::unique_lock<std::mutex> l(mu_);
     for (;;) {
-      std::function<void(int)>* job;
-      {
-        std::unique_lock<std::mutex> l(mu_);
-        cv_.wait(l, [&] { return stop_ || gen_ != seen; });
-        if (stop_) return;
-        seen = gen_;
-        job = job_;
-      }
-      for (;;) {
-        int i = next_.fetch_add(1);
-        if (i >= total_) break;
-        (*job)(i);
-      }
-      {
-        std::lock_guard<std::mutex> l(mu_);
-        if (--pending_ == 0) done_cv_.notify_all();
-      }
+      Job* job = nullptr;
+      cv_.wait(l, [&] {
+        if (stop_) return true;
+        for (Job* j : jobs_)
+          if (j->next < j->total) { job = j; return true; }
+        return false;
+      });
+      if (stop_) return;
+      const int i = job->next++;
+      if (job->next == job->total) jobs_.erase(std::find(jobs_.begin(), jobs_.end(), job));   // no items left to hand out
+      l.unlock();
+      job->fn(i);
+      l.lock();
+      if (--job->unfinished == 0) job->done_cv.notify_all();
     }
   }
   std::vector<std::thread> threads_;
   std::mutex mu_;
-  std::condition_variable cv_, done_cv_;
-  std::function<void(int)>* job_ = nullptr;
-  std::atomic<int> next_{0};
-  int total_ = 0, pending_ = 0;
-  uint64_t gen_ = 0;
+  std::condition_variable cv_;
+  std::vector<Job*> jobs_;   // oldest first
   bool stop_ = false;
 };
 
+// One game group: its engine instance, its games, and the driver thread that alternates
+// "evaluate the group's leaves" (Evaluator::Run: H2D, forward pass, D2H on the group's stream) and
+// "advance every game to its next leaf" (a ParallelFor on the shared pool).
 struct Half {
   std::unique_ptr<Evaluator> eval;
   std::vector<std::unique_ptr<GameRunner>> games;
-  std::thread gpu;
-  std::mutex mu;
-  std::condition_variable cv;
-  bool run_requested = false, run_done = false, quit = false, ok = true;
-  double gpu_seconds = 0;
-  long runs = 0;
+  std::vector<p3hip_features> feats;
+  std::thread driver;
+  // written by the driver thread only; read by the caller after the thread has been joined
+  bool ok = true;
+  double gpu_seconds = 0, host_seconds = 0;   // inside Run / inside advance, measured region only
+  long measured_batches = 0;
+  GameStats base, end;                         // game counters at the start / end of the measured region
+  std::chrono::steady_clock::time_point t_start, t_end;
 };
 
 }  // namespace p3
@@ -716,134 +724,109 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     }
   }
   WorkerPool pool(num_threads > 0 ? num_threads : 1);
-  std::vector<std::vector<p3hip_features>> feats(NG);
-  for (int h = 0; h < NG; ++h) feats[h].resize(halves[h].games.size());
+  for (int h = 0; h < NG; ++h) halves[h].feats.resize(halves[h].games.size());
 
   auto advance_half = [&](int h, bool deliver) {
     Half& H = halves[h];
-    pool.ParallelFor((int)H.games.size(), [&](int g) {
+    pool.ParallelFor((int)H.games.size(), [&H, deliver](int g) {
       if (deliver) {
         p3hip_result r;
         H.eval->Get(g, r);
         H.games[g]->DeliverResult(r);
       }
-      H.games[g]->AdvanceToEval(&feats[h][g]);
-      H.eval->Load(g, feats[h][g]);
+      H.games[g]->AdvanceToEval(&H.feats[g]);
+      H.eval->Load(g, H.feats[g]);
     });
   };
-  for (int h = 0; h < NG; ++h) {
-    Half* H = &halves[h];
-    H->gpu = std::thread([H] {
-      for (;;) {
-        std::unique_lock<std::mutex> l(H->mu);
-        H->cv.wait(l, [H] { return H->run_requested || H->quit; });
-        if (H->quit) return;
-        H->run_requested = false;
-        l.unlock();
-        auto t0 = std::chrono::steady_clock::now();
-        bool ok = H->eval->Run();
-        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        l.lock();
-        H->ok = ok;
-        H->gpu_seconds += dt;
-        ++H->runs;
-        H->run_done = true;
-        H->cv.notify_all();
-      }
-    });
-  }
-  auto request_run = [&](int h) {
-    std::lock_guard<std::mutex> l(halves[h].mu);
-    halves[h].run_done = false;
-    halves[h].run_requested = true;
-    halves[h].cv.notify_all();
-  };
-  auto wait_run = [&](int h) {
-    std::unique_lock<std::mutex> l(halves[h].mu);
-    halves[h].cv.wait(l, [&] { return halves[h].run_done; });
-    return halves[h].ok;
-  };
-  auto totals = [&](GameStats& t) {
-    t = GameStats();
-    for (auto& H : halves)
-      for (auto& g : H.games) {
-        t.moves += g->stats().moves; t.games += g->stats().games;
-        t.evals += g->stats().evals; t.black_wins += g->stats().black_wins;
-        t.cache_hits += g->stats().cache_hits;
-        t.bias_entries_pruned += g->stats().bias_entries_pruned;
-        t.bias_adj_abs_sum += g->stats().bias_adj_abs_sum;
-      }
+  auto group_totals = [](const Half& H) {
+    GameStats t;
+    for (auto& g : H.games) {
+      t.moves += g->stats().moves; t.games += g->stats().games;
+      t.evals += g->stats().evals; t.black_wins += g->stats().black_wins;
+      t.cache_hits += g->stats().cache_hits;
+      t.bias_entries_pruned += g->stats().bias_entries_pruned;
+      t.bias_adj_abs_sum += g->stats().bias_adj_abs_sum;
+    }
+    return t;
   };
 
-  int rc = 0;
+  // Every group runs on its own: warm-up batches, then its share of the measured batches (or the
+  // measured time), then unmeasured batches until every group has finished measuring, so the GPU
+  // sees the same load for the whole of every group's measured region.  A batch = advance all
+  // games of the group to their next leaf (host pool), then one engine run.
+  const long batch_limit = g_step_limit > 0 ? (g_step_limit + NG - 1) / NG : 0;   // per group
+  std::atomic<int> groups_done{0};
+  std::atomic<bool> failed{false};
   for (int h = 0; h < NG; ++h) {
-    advance_half(h, false);
-    request_run(h);
-  }
-  GameStats base;
-  double base_gpu = 0, host_seconds = 0;
-  long base_runs = 0;
-  std::chrono::steady_clock::time_point t_start;
-  bool measuring = false;
-  long iter = 0, measured_rounds = 0;
-  const long round_limit = g_step_limit > 0 ? (g_step_limit + NG - 1) / NG : 0;
-  for (;;) {
-    for (int h = 0; h < NG && rc == 0; ++h) {
-      if (!wait_run(h)) {
-        rc = 2;
-        if (err) snprintf(err, 256, "engine run failed");
-        break;
+    halves[h].driver = std::thread([&, h] {
+      Half& H = halves[h];
+      advance_half(h, false);
+      long batches = 0;
+      bool measuring = false, done = false;
+      for (;;) {
+        const auto r0 = std::chrono::steady_clock::now();
+        const bool ok = H.eval->Run();
+        const auto r1 = std::chrono::steady_clock::now();
+        ++batches;
+        // here the group's games are quiescent (results not yet delivered): counters can be read
+        if (!ok) { H.ok = false; failed.store(true); }
+        if (measuring && !done) {
+          ++H.measured_batches;
+          H.gpu_seconds += std::chrono::duration<double>(r1 - r0).count();
+          const bool enough = batch_limit > 0 ? H.measured_batches >= batch_limit
+                                              : std::chrono::duration<double>(r1 - H.t_start).count() >= seconds;
+          if (enough || failed.load()) {
+            H.t_end = r1;
+            H.end = group_totals(H);
+            done = true;
+            groups_done.fetch_add(1);
+          }
+        }
+        if (!measuring && (batches >= warmup_batches || failed.load())) {
+          // the measured region starts here: its first batch is loaded by the advance below
+          H.base = group_totals(H);
+          H.t_start = r1;
+          measuring = true;
+          if (failed.load()) { H.t_end = r1; H.end = H.base; done = true; groups_done.fetch_add(1); }
+        }
+        if (done && groups_done.load() >= NG) break;
+        const auto a0 = std::chrono::steady_clock::now();
+        advance_half(h, true);
+        if (measuring && !done) H.host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
       }
-      auto a0 = std::chrono::steady_clock::now();
-      advance_half(h, true);
-      host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
-      request_run(h);
-    }
-    if (rc) break;
-    ++iter;
-    if (!measuring && iter >= warmup_batches) {
-      totals(base);
-      base_gpu = 0; base_runs = 0;
-      for (auto& H : halves) { base_gpu += H.gpu_seconds; base_runs += H.runs; }
-      host_seconds = 0;
-      t_start = std::chrono::steady_clock::now();
-      measuring = true;
-    }
-    else if (measuring) ++measured_rounds;
-    if (measuring && round_limit > 0) {
-      if (measured_rounds >= round_limit) break;
-    } else if (measuring && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= seconds) {
-      break;
-    }
+    });
   }
-  for (int h = 0; h < NG; ++h) wait_run(h);
-  double secs = measuring ? std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() : 0;
-  for (auto& H : halves) {
-    {
-      std::lock_guard<std::mutex> l(H.mu);
-      H.quit = true;
+  for (auto& H : halves) H.driver.join();
+  int rc = 0;
+  for (auto& H : halves)
+    if (!H.ok) {
+      rc = 2;
+      if (err) snprintf(err, 256, "engine run failed");
     }
-    H.cv.notify_all();
-    H.gpu.join();
-  }
   if (recorder) recorder->Flush();
   g_last_reuse_added = reuse->added();
   g_last_examples = recorder ? recorder->examples() : 0;
   if (out) {
-    GameStats t;
-    totals(t);
-    out->seconds = secs;
-    out->positions = t.evals - base.evals;
-    out->moves = t.moves - base.moves;
-    out->games = t.games - base.games;
-    out->black_wins = t.black_wins - base.black_wins;
-    out->batches = -base_runs;
-    out->gpu_seconds = -base_gpu;
-    for (auto& H : halves) { out->batches += H.runs; out->gpu_seconds += H.gpu_seconds; }
-    out->host_seconds = host_seconds;
-    out->cache_hits = t.cache_hits - base.cache_hits;
-    g_last_bias_pruned = t.bias_entries_pruned - base.bias_entries_pruned;
-    g_last_bias_adj = t.bias_adj_abs_sum - base.bias_adj_abs_sum;
+    std::memset(out, 0, sizeof *out);
+    g_last_bias_pruned = 0;
+    g_last_bias_adj = 0;
+    // the job's clock: from the first group that started measuring to the last that finished
+    auto t0 = halves[0].t_start, t1 = halves[0].t_end;
+    for (auto& H : halves) {
+      if (H.t_start < t0) t0 = H.t_start;
+      if (H.t_end > t1) t1 = H.t_end;
+      out->positions += H.end.evals - H.base.evals;
+      out->moves += H.end.moves - H.base.moves;
+      out->games += H.end.games - H.base.games;
+      out->black_wins += H.end.black_wins - H.base.black_wins;
+      out->cache_hits += H.end.cache_hits - H.base.cache_hits;
+      out->batches += H.measured_batches;
+      out->gpu_seconds += H.gpu_seconds;
+      out->host_seconds += H.host_seconds;
+      g_last_bias_pruned += H.end.bias_entries_pruned - H.base.bias_entries_pruned;
+      g_last_bias_adj += H.end.bias_adj_abs_sum - H.base.bias_adj_abs_sum;
+    }
+    out->seconds = std::chrono::duration<double>(t1 - t0).count();
   }
   return rc;
 }

@@ -351,8 +351,8 @@ def test_move_sel_manager_known_answers(host):
 def test_selfplay_host_over_the_cpu_engine_and_step_limit(built, weight_files):
     """The CPU baseline leg of bench.py: the same self-play host binds the CPU fp32 oracle through
     the same C ABI (oracle/libp3cpu_engine.so, loaded with dlopen exactly like libp3hip.so), and
-    with a step limit the timed region is exactly `steps` engine batches: `steps` batches' worth of
-    leaf positions are loaded in it (+ the one batch per group in flight when it ends)."""
+    with a step limit the timed region is exactly `steps` engine batches (each group its share):
+    `steps` batches' worth of leaf positions are loaded and evaluated in it."""
     import os
     from conftest import ROOT
     from p3achygo_amd import host_api
@@ -367,7 +367,7 @@ def test_selfplay_host_over_the_cpu_engine_and_step_limit(built, weight_files):
                                    warmup_batches=1, seed=3, engine_lib=lib)
     finally:
         host_api.set_step_limit(0)
-    assert st.batches == 6 + 2                       # 3 rounds x 2 groups, + the drain of the last round
+    assert st.batches == 6                           # 3 batches for each of the 2 groups
     assert 0 < st.positions <= 6 * 8                 # at most one full batch of 8 games per step
     assert st.positions >= 6 * 8 - 16                # terminal / cached leaves leave a few slots empty
     assert st.seconds > 0

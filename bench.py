@@ -37,7 +37,7 @@ MODEL = "b12c256btl3"
 BATCH = 1024
 GROUPS = 4          # game groups per GPU: 3 forward passes queued while the 4th group is on the host
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 PF
-LADDER_BUDGET = 20000   # self-play throughput mode of the ladder read-out (host_api.set_ladder_budget)
+LADDER_BUDGET = 0       # ladder read-out work bound of the host: 0 = the reference's exact read-out (default)
 
 
 def make_positions(n, seed):
@@ -117,7 +117,8 @@ def main():
     ap.add_argument("--model", default=MODEL)
     ap.add_argument("--engine-steps", type=int, default=200, help="timed steps of the engine-only leg")
     ap.add_argument("--ladder-budget", type=int, default=LADDER_BUDGET,
-                    help="ladder read-out work bound of the self-play host (0 = reference-exact)")
+                    help="ladder read-out work bound of the self-play host (0 = reference-exact, the default; "
+                         "> 0 = the opt-in throughput mode, hits are reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -164,6 +164,127 @@ __device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS, G
   }
 }
 
+// The 3x3 segment with the activation fragments of a kernel row's three taps shared.
+//
+// Rows of a tile pair are interleaved (even tile = rows base + 2n, odd tile = base + 2n + 1), so for
+// kernel row ky and k32 index q32 the six (tile, kx) operands of a pair are only FOUR different
+// fragments R[s] = slots base + 2n + s, s = 0..3 (s = kx + parity): the even tile's fragment at
+// kx + 1 is the odd tile's at kx.  Steps therefore run (ky, q32, kx) instead of (ky, kx, q32) —
+// the fused blocks' 3x3 weights are packed in that order (engine.cpp pack_segment_3x3) — and a
+// group of three steps (72 MFMAs) loads 12 activation + 12 weight fragments instead of 18 + 12:
+// a fifth fewer LDS reads per MFMA.  The kernel is power-limited: what this
+// buys is energy, i.e. clock.
+//
+// Schedule.  Fragments of group g + 1 are loaded during group g, each into the register its
+// predecessor just vacated: R[.][0] is dead after step kx = 0 (even tile), R[.][1] after kx = 1,
+// R[.][2] and R[.][3] after kx = 2; every reload has two or more steps to land.  The weight
+// fragments of step u + 1 are loaded during step u after location groups 0 and 1 (double
+// buffer), as in conv_segment16.  One counted wait per step, at its start: everything but the
+// activation reloads issued after the previous step's last weight read must have landed — the
+// fragments a step uses are all older than that.
+template <class G, int COUT_PASS, int NTn = 0>
+__device__ __forceinline__ void conv_segment16_3x3(Ring<ring_slot_bytes(COUT_PASS, G::KMS), G::NW>& ring, char* smem,
+                                                   f32x4 (&acc)[4][NTn]) {
+  using T = Tiling16<G, COUT_PASS>;
+  static_assert(NTn == T::NT && T::NT == 6 && G::CB % 32 == 0, "shape");
+  constexpr int NB = 3;
+  constexpr int NQ = G::CB / 32;                   // k32 steps per tap
+  constexpr int U = 3 * NQ;                        // one kernel row: NQ groups of three steps
+  constexpr int NOUT = 3;
+  constexpr int KM32 = G::KMS / 2;
+  static_assert(U % 2 == 0 && U % KM32 == 0, "segment shape");
+  constexpr int KB = COUT_PASS * 32;
+  const int lane = launder(threadIdx.x & 63);
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = wid % T::CG, lg = wid / T::CG;
+  const int n = lane & 15, q = lane >> 4;
+  const uint32_t a_off = (uint32_t)((q >> 1) * KB + ((q & 1) * COUT_PASS + cg * 64 + n) * 16);
+  uint32_t a_addr = 0;
+  uint32_t b_row[NB];
+  h8 fa[2][4], fr[NB][4];
+
+  auto set_rows = [&](int ky) {   // leftmost tap of kernel row ky, even tile of each pair
+    const int rowshift = (ky - 1) * G::S - 1;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      b_row[b] = (uint32_t)((tile16_slot0<G, COUT_PASS>(lg, 2 * b) + 2 * n + rowshift) * G::SLOTB + q * 16);
+  };
+  // weight fragments 2*JJ, 2*JJ+1 of static step V (V may be U = step 0 of the next body)
+  auto a_fetch = [&](auto V, auto JJ) {
+    constexpr int v = decltype(V)::value, jj = decltype(JJ)::value;
+    constexpr int kk = (v % U) % KM32;
+    constexpr int nxt = v % 2;
+    // every weight read of the slot being recycled landed before this step's MFMAs began (the wait
+    // at the step's start); up to five younger activation reloads may stay in flight
+    if constexpr (jj == 0 && kk == 0) a_addr = ring_acquire<5>(ring, smem) + a_off;
+    constexpr int AOFF = kk * 2 * KB + jj * 512;
+    fa[nxt][2 * jj] = lds_read128<AOFF>(a_addr);
+    fa[nxt][2 * jj + 1] = lds_read128<AOFF + 256>(a_addr);
+  };
+  // activation fragment R[B][S] of the group with k32 index Q32 (rows set by set_rows)
+  auto b_fetch = [&](auto B, auto S, auto Q32) {
+    constexpr int b = decltype(B)::value, sidx = decltype(S)::value, q32 = decltype(Q32)::value;
+    fr[b][sidx] = lds_read128<sidx * G::SLOTB + q32 * 64>(b_row[b]);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // prologue: the first acquire is also the "previous layer written" barrier — reads come after it
+  set_rows(0);
+  a_addr = ring_acquire<0>(ring, smem) + a_off;
+  {
+    constexpr int AOFF = 0;
+    fa[0][0] = lds_read128<AOFF>(a_addr);
+    fa[0][1] = lds_read128<AOFF + 256>(a_addr);
+    fa[0][2] = lds_read128<AOFF + 512>(a_addr);
+    fa[0][3] = lds_read128<AOFF + 768>(a_addr);
+  }
+  static_for<0, NB>([&](auto B) { static_for<0, 4>([&](auto S) { b_fetch(B, S, I0{}); }); });
+
+#pragma unroll 1
+  for (int o = 0; o < NOUT; ++o) {
+    const bool last_body = o + 1 == NOUT;
+    static_for<0, U>([&](auto UU) {
+      constexpr int u = decltype(UU)::value;
+      constexpr int q32 = u / 3, kx = u % 3;
+      constexpr bool last_group = q32 == NQ - 1;
+      const bool a_next = (u + 1 < U) || !last_body;            // a step follows: load its weight fragments
+      const bool b_next = !(last_group && last_body);           // a group follows: reload this group's fragments
+      // what may still be in flight: the reloads the previous step issued after its last weight read
+      if constexpr (u == 0) {
+        if (o == 0) wait_lgkm<0>(); else wait_lgkm<4>();
+      } else {
+        constexpr bool prev_last_group = (u - 1) / 3 == NQ - 1;
+        constexpr int n_prev = ((u - 1) % 3 == 2) ? 4 : 2;
+        if (prev_last_group && last_body) wait_lgkm<0>(); else wait_lgkm<n_prev>();
+      }
+      // the reloads of a body's last group belong to the next kernel row
+      if constexpr (last_group && kx == 0) { if (b_next) set_rows(o + 1); }
+      using QN = std::integral_constant<int, (q32 + 1) % NQ>;
+      static_for<0, 6>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[u % 2][ct], fr[j >> 1][kx + (j & 1)], acc[ct][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        using B = std::integral_constant<int, j / 2>;
+        if constexpr (j % 2 == 0) {              // the even tile was the last user of R[b][kx]
+          if constexpr (j == 0) {
+            if (b_next) b_fetch(B{}, std::integral_constant<int, kx>{}, QN{});
+            if (a_next) a_fetch(std::integral_constant<int, u + 1>{}, I0{});
+          } else {
+            if (b_next) b_fetch(B{}, std::integral_constant<int, kx>{}, QN{});
+          }
+        } else {
+          if constexpr (kx == 2) { if (b_next) b_fetch(B{}, std::integral_constant<int, 3>{}, QN{}); }   // the odd tile of the last step: R[b][3]
+          if constexpr (j == 1) { if (a_next) a_fetch(std::integral_constant<int, u + 1>{}, I1{}); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  }
+}
+
 // ---- epilogues ---------------------------------------------------------------------------
 struct EpiParams16 { f32x4 sc[4], sh[4]; };
 

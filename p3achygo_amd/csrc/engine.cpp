@@ -145,6 +145,24 @@ void pack_segment(std::vector<_Float16>& dst, const float* W, int taps, int ntap
           }
 }
 
+// 3x3 weights of the fused block kernel: k16 blocks in (kernel row, k32 index, kernel column)
+// order — the three taps of a kernel row share their activation fragments (conv16.h
+// conv_segment16_3x3), so a step advances the column before the channel slice.
+void pack_segment_3x3(std::vector<_Float16>& dst, const float* W, int cin_total, int cout_total, int CB, int CP) {
+  for (int ky = 0; ky < 3; ++ky)
+    for (int q32 = 0; q32 < CB / 32; ++q32)
+      for (int kx = 0; kx < 3; ++kx)
+        for (int q = 2 * q32; q < 2 * q32 + 2; ++q)
+          for (int h = 0; h < 2; ++h)
+            for (int co = 0; co < CP; ++co)
+              for (int e = 0; e < 8; ++e) {
+                const int ci = q * 16 + h * 8 + e, tap = ky * 3 + kx;
+                float v = 0.0f;
+                if (ci < cin_total && co < cout_total) v = W[((size_t)tap * cin_total + ci) * cout_total + co];
+                dst.push_back((_Float16)v);
+              }
+}
+
 struct FoldedBN { size_t scale_off, shift_off; };
 
 // One conv launch of a layer-wise block (kind 4).  Regions: 0 = x; 1, 2 = the two C_b-channel
@@ -370,7 +388,7 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
       for (int j = 0; j < nconv; ++j) bp.bn[j] = fold_bn(ar, wf, p + ".bn" + std::to_string(j), j == 0 ? C : Cb);
       std::vector<_Float16> s;
       for (int ip = 0; ip < C / CB; ++ip) pack_segment(s, W(0, 1, C, Cb), 1, 1, C, Cb, ip * CB, CB, 0, CB);
-      for (int j = 1; j < nconv - 1; ++j) pack_segment(s, W(j, 3, Cb, Cb), 9, 9, Cb, Cb, 0, CB, 0, CB);
+      for (int j = 1; j < nconv - 1; ++j) pack_segment_3x3(s, W(j, 3, Cb, Cb), Cb, Cb, CB, CB);
       for (int cp = 0; cp < C / CB; ++cp) pack_segment(s, W(nconv - 1, 1, Cb, C), 1, 1, Cb, C, 0, CB, cp * CB, CB);
       run_streams.emplace_back(e->blocks.size(), std::move(s));
     }

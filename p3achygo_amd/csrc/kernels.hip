@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
         for (int j = 1; j <= L; ++j) {
           epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[j], bp.shift[j]);
           acc16_zero<NT>(acc);
-          conv_segment16<G, CB, 3, 9>(ring, smem, acc);
+          conv_segment16_3x3<G, CB>(ring, smem, acc);
         }
         epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[L + 1], bp.shift[L + 1]);
       } else {
@@ -116,10 +116,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           acc16_zero<NT>(acc);
-          conv_segment16<G, CB, 3, 9>(ring, smem, acc);
+          conv_segment16_3x3<G, CB>(ring, smem, acc);
           epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[2 + 2 * r], bp.shift[2 + 2 * r]);
           acc16_zero<NT>(acc);
-          conv_segment16<G, CB, 3, 9>(ring, smem, acc);
+          conv_segment16_3x3<G, CB>(ring, smem, acc);
           // t is fetched after the K loop: holding it across the 3x3 loop costs more (spills of
           // the loaded values, i.e. the same exposed latency plus scratch traffic)
           residual_addr16<G, CB, NT>(tr, CB, pos0, a.npos, 0);

@@ -160,6 +160,8 @@ void p3host_test_bias_cache_math(float alpha, float lambda, const float* init, c
 
 // k > 0: Gumbel root search (n, k); k == 0: SearchRootPuct with n playouts (self-play's
 // fast-move parameters).
+static bool g_scripted_early_stopping = false;
+extern "C" void p3host_test_scripted_early_stopping(int on) { g_scripted_early_stopping = on != 0; }
 extern "C" int p3host_test_scripted_search(int n, int k, int* child_visits, float* child_q, int* nn_move,
                                            int* mcts_move, int* root_n) {
   Game game(7.5f, true);
@@ -168,6 +170,7 @@ extern "C" int p3host_test_scripted_search(int n, int k, int* child_visits, floa
   Probability prob(0);
   GumbelParams p;
   p.n = n; p.k = k; p.noise_scaling = 0.0f; p.tau = 0.0f;
+  p.early_stopping_enabled = g_scripted_early_stopping;
   GumbelSearch search;
   if (k > 0) {
     search.Begin(&game, &pool, root, kBlack, p, &prob);
@@ -400,6 +403,22 @@ void p3host_test_ladder_modes(int n_positions, uint64_t seed, long budget, int f
 #include "selfplay_policy.h"
 
 extern "C" {
+// A book start (BookInitState): out[0] stones on the board, out[1] colour to move, out[2] kind,
+// out[3] move_num, out[4] number of non-noop last moves; last5 = encoded last moves (i*19+j, noop -20).
+void p3host_test_book_state(uint64_t seed, int* out, int* last5) {
+  Probability prob(seed);
+  InitState s0;
+  s0.board = Board(7.5f, true);
+  const InitState s = BookInitState(prob, s0);
+  int stones = 0, nm = 0;
+  for (Color c : s.board.position()) stones += c != kEmpty;
+  for (int i = 0; i < 5; ++i) {
+    last5[i] = s.last_moves[i].loc == kNoopLoc ? -20 : s.last_moves[i].loc.i * 19 + s.last_moves[i].loc.j;
+    nm += s.last_moves[i].loc != kNoopLoc;
+  }
+  out[0] = stones; out[1] = s.color_to_move; out[2] = (int)s.kind; out[3] = s.move_num; out[4] = nm;
+}
+
 // Plays `n_moves` scripted legal moves (first empty point scanning from a seed-dependent
 // offset), calling MaybeFork before each; network evaluations are answered by a scripted
 // result whose policy is uniform over the board, win probability `p_win` and a one-hot score

@@ -385,6 +385,16 @@ inline std::pair<float, float> ConfidenceInterval(const TreeNode* node, int a) {
 }
 inline float Lcb(const TreeNode* node, int a) { return ConfidenceInterval(node, a).first; }
 inline float Ucb(const TreeNode* node, int a) { return ConfidenceInterval(node, a).second; }
+// the same interval at another significance level (tree.cc:34-50: ZScore = upper alpha/2 quantile)
+inline std::pair<float, float> ConfidenceIntervalAlpha(const TreeNode* node, int a, float alpha) {
+  if (std::abs(alpha - kLcbAlpha) < 1e-5f) return ConfidenceInterval(node, a);
+  const float n = (float)node->child_visits(a);
+  const TreeNode* ch = node->child(a);
+  if (!ch || n < 2) return {-1e6f + n, 1e6f - n};
+  const float stddev = std::sqrt(VVar(ch) / n);
+  const float z = (float)StudentTUpperQuantile((double)((int)n - 1), alpha / 2);
+  return {Q(node, a) - z * stddev, Q(node, a) + z * stddev};
+}
 
 // Public ComputeImprovedPolicy(node, n) / ComputeKLD of the reference (gumbel.cc:172-204),
 // used by the self-play loop for its pre-/post-search KL statistics.
@@ -475,6 +485,7 @@ struct GumbelParams {   // GumbelSearchParams, cc/mcts/gumbel.h:41-57
   bool disable_pass = false;
   float tau = 0.0f;
   int nonroot_var_scale_prior_visits = 10;
+  bool early_stopping_enabled = false;   // gumbel.h:46 (--early_stopping_enabled, off by default)
 };
 
 struct GumbelResult {   // cc/mcts/gumbel.h:31-39 (subset)
@@ -627,11 +638,43 @@ class GumbelSearch {
         round_open_ = true;
         if (visits_per_action_ <= 0) { CloseRound(); continue; }
       }
-      if (cand_ >= k_) { cand_ = 0; ++visit_num_; }
+      if (cand_ >= k_) {
+        // a sweep over the round's candidates is complete: early-stopping check every
+        // ceil(v / 4) sweeps (gumbel.cc:396-407,459-466)
+        if (p_.early_stopping_enabled) {
+          const int interval = (visits_per_action_ + 3) / 4;
+          if (interval > 0 && visit_num_ % interval == interval - 1 && visit_num_ >= interval - 1) {
+            for (int i = 0; i < k_; ++i)
+              if (gm_[i].enc >= 0) gm_[i].qtransform = (kVisit + MaxN(root_)) * -V(root_->child(gm_[i].enc));
+            std::sort(gm_, gm_ + k_, Greater);
+            if (CanStopEarly()) { CloseRound(); continue; }
+          }
+        }
+        cand_ = 0;
+        ++visit_num_;
+      }
       if (visit_num_ >= visits_per_action_) { CloseRound(); continue; }
       if (gm_[cand_].enc < 0) { ++cand_; continue; }
       return true;
     }
+  }
+  // can_stop_early (gumbel.cc:323-351): with the candidates sorted, no move of the half about to
+  // be dropped can still be the best one — its upper bound is below the best lower bound of the
+  // half that stays — at significance lambda / ceil(k / 2), lambda = 0.95^(1 / rounds) (sic);
+  // every candidate needs kMinEarlyStoppingVisits = 10 visits first.
+  bool CanStopEarly() const {
+    const float lambda = std::pow(0.95f, 1.0f / num_rounds_);
+    const int kb = k_ / 2 + k_ % 2;
+    float top_lcb = -2, bot_ucb = -2;
+    for (int i = 0; i < k_; ++i) {
+      const int a = gm_[i].enc;
+      if (a < 0) continue;
+      if (!root_->child(a) || root_->child_visits(a) < 10) return false;
+      const auto ci = ConfidenceIntervalAlpha(root_, a, lambda / kb);
+      if (i < k_ / 2) top_lcb = std::max(top_lcb, ci.first);
+      else bot_ucb = std::max(bot_ucb, ci.second);
+    }
+    return bot_ucb <= top_lcb;
   }
   void CloseRound() {   // gumbel.cc:470-473
     for (int i = 0; i < k_; ++i)

@@ -125,6 +125,7 @@ struct SelfPlayConfig {       // SPConfig, cc/selfplay/self_play_thread.h:38-61
   int max_moves = 600;                    // --max_moves
   int nonroot_var_scale_prior_visits = 10;
   float bias_cache_lambda = 0.0f, bias_cache_alpha = 0.8f;   // --bias_cache_{lambda,alpha} main.cc:58-61 (0 = off)
+  bool early_stopping_enabled = false;                       // --early_stopping_enabled main.cc:68
   float use_seen_state_prob = 0.5f;       // --use_seen_state_prob     main.cc:48-50
   float sel_mult_base = 0.0f, sel_mult_scale_factor = 1.0f;   // main.cc:51-57
   ForkParams fork_params = ForkParams::ForReuse(0.5f);        // main.cc:191-193
@@ -374,6 +375,7 @@ class GameRunner {
     pre_.selected = selected;
     GumbelParams p;
     p.nonroot_var_scale_prior_visits = cfg_.nonroot_var_scale_prior_visits;
+    p.early_stopping_enabled = cfg_.early_stopping_enabled;   // (!is_move_over_search: over-search is dead code, :544-548)
     if (force_first_move) {
       p.n = cfg_.selected_n; p.k = cfg_.selected_k;
     } else if (sampling_raw_policy) {
@@ -599,6 +601,7 @@ int g_rec_gen = 0, g_rec_flush_interval = 128;   // --flush_interval, selfplay/m
 bool g_init_state_sampling = true;
 float g_use_seen_state_prob = 0.5f, g_sel_mult_base = 0.0f, g_sel_mult_scale = 1.0f;
 float g_bias_cache_lambda = 0.0f, g_bias_cache_alpha = 0.8f;
+bool g_early_stopping = false;
 long g_last_bias_pruned = 0;
 double g_last_bias_adj = 0;
 int g_num_groups = 2;
@@ -624,6 +627,8 @@ void p3host_selfplay_set_bias_cache(float lambda, float alpha) {
   g_bias_cache_lambda = lambda;
   g_bias_cache_alpha = alpha;
 }
+// --early_stopping_enabled of subsequent runs (selfplay/main.cc:68,260; off by default)
+void p3host_selfplay_set_early_stopping(int enabled) { g_early_stopping = enabled != 0; }
 // bias-cache entries pruned / sum of |root adjustment| over the moves of the last run or game
 long p3host_selfplay_last_bias_pruned() { return g_last_bias_pruned; }
 double p3host_selfplay_last_bias_adj() { return g_last_bias_adj; }
@@ -691,6 +696,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   cfg.sel_mult_scale_factor = g_sel_mult_scale;
   cfg.bias_cache_lambda = g_bias_cache_lambda;
   cfg.bias_cache_alpha = g_bias_cache_alpha;
+  cfg.early_stopping_enabled = g_early_stopping;
   cfg.fork_params = ForkParams::ForReuse(g_use_seen_state_prob);
   auto reuse = std::make_unique<ReuseBuffer>(seed ^ 0x676f6578706c6f69ull);
   cfg.reuse = reuse.get();

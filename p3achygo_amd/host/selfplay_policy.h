@@ -82,6 +82,29 @@ class ReuseBuffer {
 constexpr float kPlayFromBookProb = 0.0f;   // self_play_thread.cc:50 (the opening book is never used)
 constexpr float kHandicapGameProb = 0.05f;  // :53
 
+// The opening book (cc/selfplay/book.h: six four-move openings; data).  Line 3 repeats a point:
+// the second stone there is an illegal move that the reference plays unchecked (the board
+// rejects it, the move list keeps it) — kept as is.
+constexpr int kOpeningBook[6][4][2] = {
+    {{3, 3}, {15, 15}, {15, 4}, {4, 15}}, {{3, 3}, {15, 15}, {16, 4}, {4, 15}}, {{3, 3}, {15, 4}, {15, 16}, {15, 4}},
+    {{3, 3}, {15, 4}, {15, 15}, {4, 15}}, {{3, 3}, {15, 15}, {2, 15}, {15, 15}}, {{3, 3}, {15, 15}, {2, 15}, {16, 15}}};
+
+// A start from the book (self_play_thread.cc:216-233): a random line, a random prefix of 0..4 moves
+// (round of a uniform draw), played from the empty board at the sampled komi.
+inline InitState BookInitState(Probability& prob, InitState s0) {
+  const int index = (int)(prob.Uniform() * 6);
+  const int num_moves = (int)std::round(prob.Uniform() * 4);
+  s0.kind = InitState::Kind::kBook;
+  for (int i = 0; i < 5; ++i) s0.last_moves[i] = kNoopMove;
+  for (int i = 0; i < num_moves; ++i) {
+    const Loc loc{kOpeningBook[index][i][0], kOpeningBook[index][i][1]};
+    (void)s0.board.PlayMove(loc, s0.color_to_move);
+    s0.last_moves[5 - num_moves + i] = Move{s0.color_to_move, loc};
+    s0.color_to_move = Opp(s0.color_to_move);
+  }
+  return s0;
+}
+
 // self_play_thread.cc:202-252
 inline InitState GetInitState(Probability& prob, ReuseBuffer* buffer, float use_seen_state_prob) {
   const float komi = std::round(7.0f + std::clamp(prob.Gaussian(), -3.0f, 3.0f)) + (prob.Uniform() < 0.5f ? -0.5f : 0.5f);
@@ -89,9 +112,8 @@ inline InitState GetInitState(Probability& prob, ReuseBuffer* buffer, float use_
   s0.board = Board(komi, true);
   const float p = prob.Uniform();
   if (p <= kPlayFromBookProb) {
-    // kPlayFromBookProb = 0: p <= 0 only for p == 0 exactly; the reference would then index
-    // its opening book (cc/selfplay/book.h).  Treated as an empty game.
-    return s0;
+    // kPlayFromBookProb = 0: taken only when the uniform draw is exactly 0 (probability 2^-23)
+    return BookInitState(prob, s0);
   } else if (p <= kPlayFromBookProb + kHandicapGameProb) {
     const int handicap = (int)std::floor(prob.Uniform() * 3 + 2);
     const float hkomi = (handicap - 2) * 14 + 20.5f;

@@ -163,6 +163,13 @@ def set_bias_cache(bias_cache_lambda: float = 0.0, bias_cache_alpha: float = 0.8
     L.p3host_selfplay_set_bias_cache(bias_cache_lambda, bias_cache_alpha)
 
 
+def set_early_stopping(enabled: bool) -> None:
+    """--early_stopping_enabled of subsequent self-play runs (selfplay/main.cc:68; off by default)."""
+    L = lib()
+    L.p3host_selfplay_set_early_stopping.argtypes = [C.c_int]
+    L.p3host_selfplay_set_early_stopping(int(enabled))
+
+
 def last_bias_counters():
     """(bias-cache entries pruned, sum over moves of |root adjustment|) of the last run / game."""
     L = lib()

@@ -396,3 +396,50 @@ def test_baseline_config_c1_plumbing_on_the_cpu_engine(built, weight_files):
         host_api.set_ladder_budget(20000)
     assert len(mv) == 6 and len(set(int(m) for m in mv)) == 6 and all(m != 0 for m in mv)
     assert 6 <= ev <= 6 * 9                              # root + at most n leaves per move
+
+
+def test_gumbel_early_stopping(host):
+    """GumbelSearchParams::early_stopping_enabled (gumbel.cc:323-351,396-466; off by default): every
+    ceil(v / 4) sweeps of a halving round the candidates are re-ranked, and the round ends as soon
+    as — every candidate having 10 visits — no upper confidence bound of the half to be dropped
+    reaches the best lower bound of the half that stays.  The scripted scenario of the known-answer
+    test separates its four candidates by a third of the value range, so with a large budget the
+    search stops far short of n and still picks the same move."""
+    L = host.lib()
+    cv = (C.c_int * 4)()
+    cq = (C.c_float * 4)()
+    nn, mc, rn = C.c_int(), C.c_int(), C.c_int()
+    rc = L.p3host_test_scripted_search(400, 4, cv, cq, C.byref(nn), C.byref(mc), C.byref(rn))
+    assert rc >> 8 == 400 and mc.value == 3
+    full = list(cv)
+    L.p3host_test_scripted_early_stopping(1)
+    try:
+        rc = L.p3host_test_scripted_search(400, 4, cv, cq, C.byref(nn), C.byref(mc), C.byref(rn))
+    finally:
+        L.p3host_test_scripted_early_stopping(0)
+    assert 40 <= rc >> 8 < 250 and mc.value == 3       # both rounds end at their first or second check
+    assert all(v >= 10 for v in cv) and sum(cv) < sum(full)
+
+
+def test_opening_book_start(host):
+    """The book branch of GetInitState (self_play_thread.cc:216-233, cc/selfplay/book.h; its
+    probability constant is 0, so it is taken only when the uniform draw is exactly 0): a random
+    prefix of 0..4 moves of one of six openings, played from the empty board, colours alternating,
+    the last-move window filled from the back, move_num left at 0."""
+    L = host.lib()
+    L.p3host_test_book_state.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p]
+    book_points = {3 * 19 + 3, 15 * 19 + 15, 15 * 19 + 4, 4 * 19 + 15, 16 * 19 + 4, 15 * 19 + 16, 2 * 19 + 15, 16 * 19 + 15}
+    lens = set()
+    for seed in range(60):
+        out, last5 = (C.c_int * 5)(), (C.c_int * 5)()
+        L.p3host_test_book_state(seed, out, last5)
+        stones, color, kind, move_num, nm = list(out)
+        assert kind == 1 and move_num == 0 and 0 <= nm <= 4
+        assert color == (1 if nm % 2 == 0 else -1)
+        assert stones in (nm, nm - 1)                      # line 3 repeats a point: that stone is rejected
+        moves = [m for m in last5 if m != -20]
+        assert list(last5[:5 - nm]) == [-20] * (5 - nm) and all(m in book_points for m in moves)
+        if nm:
+            assert moves[0] == 3 * 19 + 3
+        lens.add(nm)
+    assert lens == {0, 1, 2, 3, 4}

@@ -117,6 +117,8 @@ if __name__ == "__main__":
     dump_nn("test_b3c384btl3", 3, 18)
     dump_nn("test_b3c384nbt", 3, 19)
     dump_nn("test_b3c192classic", 3, 20)
+    dump_nn("test_b5c256nbt_i2", 3, 25)
+    dump_nn("test_b5c128btl1_i2", 3, 26)
     # full-size BASELINE architectures: wide position sets; outputs stored as float32 (the
     # float64 results rounded once: 6e-8 relative, three orders below any tolerance)
     dump_nn("b8c128nbt", 8, 14, wide=True, store=np.float32)                  # C1

@@ -501,6 +501,16 @@ __device__ __forceinline__ void activate_stashed16(EpiOut16<NTn>& A, const float
   }
 }
 
+// A half fetched in the piece layout that goes into the act buffer as it is (the input of a
+// fused broadcast conv_last is already activated by k_bdense): piece halves -> accumulator quads.
+template <int NTn>
+__device__ __forceinline__ void unstash16(EpiOut16<NTn>& A) {
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int b = 0; b < NTn / 2; ++b) half_swap(A.o[2 * b][ct], A.o[2 * b + 1][ct]);
+}
+
 // Expand epilogue of the position-major block kernel: x' = acc + residual -> fp16 -> HBM, and,
 // when `act`, A = mish(bn0_next(x')) of the same fp16 values for the next block's reduce (cofs =
 // channel half of this pass; scale/shift = the next block's folded bn0).
@@ -539,6 +549,28 @@ __device__ __forceinline__ void epilogue_store16_act(f32x4 (&acc)[4][NTn], const
       half_swap(o0, o1);   // every lane takes part: partners of invalid rows may be valid
       const h8 piece = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
       if (rr.ok[b]) *(h8*)(xc + (uint32_t)(rr.base[b] * 2u)) = piece;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// out = mish(acc) -> fp16 global (the broadcast block's conv_first + its activation, fused into
+// the tail of a block launch; same arithmetic as k_conv1x1's EPI 0).
+template <int NTn>
+__device__ __forceinline__ void epilogue_store16_mish(f32x4 (&acc)[4][NTn], const ResRegs16<NTn>& rr,
+                                                      _Float16* __restrict__ out) {
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    char* oc = (char*)out + (size_t)ct * (2 * kNLoc * 8 * 2);
+#pragma unroll
+    for (int b = 0; b < NTn / 2; ++b) {
+      const f32x2 a0 = mish_f2(f32x2{acc[ct][2 * b][0], acc[ct][2 * b][1]}), a1 = mish_f2(f32x2{acc[ct][2 * b][2], acc[ct][2 * b][3]});
+      const f32x2 b0 = mish_f2(f32x2{acc[ct][2 * b + 1][0], acc[ct][2 * b + 1][1]}), b1 = mish_f2(f32x2{acc[ct][2 * b + 1][2], acc[ct][2 * b + 1][3]});
+      h4 o0 = {(_Float16)a0[0], (_Float16)a0[1], (_Float16)a1[0], (_Float16)a1[1]};
+      h4 o1 = {(_Float16)b0[0], (_Float16)b0[1], (_Float16)b1[0], (_Float16)b1[1]};
+      half_swap(o0, o1);   // every lane takes part
+      const h8 piece = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+      if (rr.ok[b]) *(h8*)(oc + (uint32_t)(rr.base[b] * 2u)) = piece;
     }
     __builtin_amdgcn_sched_barrier(0);
   }

@@ -187,6 +187,14 @@ struct BlockPlan {
   size_t stream2_off = 0, stream3_off = 0;
   int nms2 = 0, nms3 = 0;
   size_t dense_bias_off = 0;
+  // Broadcast 1x1 convs taken into the neighbouring block launches (k_block's BC form).
+  //   on a broadcast block: its conv_first runs at the tail of the launch before it / its conv_last
+  //   at the head of the launch after it;
+  //   on a fused block: the run's first block carries the head conv (head_of = that broadcast block,
+  //   its stream lies right before stream_off), the run's last block the tail conv (right after).
+  bool first_fused = false, last_fused = false;
+  int head_of = -1, tail_of = -1;
+  size_t head_bytes = 0, tail_bytes = 0;
 };
 
 }  // namespace
@@ -198,6 +206,7 @@ struct p3hip_engine {
   WeightFile wf;
   int n_cu = 256;
   bool c128_wg8 = false;   // P3HIP_C128_WG8: C = 128 blocks as one 8-wave workgroup per CU (A/B timing)
+  bool bcast_fuse = true;  // P3HIP_NO_BFUSE clears it: broadcast 1x1 convs as their own launches (A/B, tests)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // p3hip_time_trunk_kernel: event pairs around every fused-block launch of a forward pass
@@ -217,6 +226,7 @@ struct p3hip_engine {
   unsigned char* h_feats_compact = nullptr;  // pinned, dense
   unsigned char* d_feats = nullptr;
   _Float16 *d_x = nullptr, *d_t = nullptr, *d_u = nullptr;
+  _Float16* d_s = nullptr;   // nbt trunks: the block kernel's inner-stream scratch (t and u carry the broadcast blocks' tensors)
   float* d_hp = nullptr;
   float* d_out = nullptr;
   float* h_out = nullptr;  // pinned [batch][kResultFloats]
@@ -295,18 +305,39 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
   // The weight streams of consecutive fused blocks go into the arena back to back, after the
   // run's other tensors: one k_block launch walks the streams of all its blocks as ONE circular
   // stream (position-major order, kernels.hip), so a run must be contiguous.
+  // With the broadcast 1x1 convs fused in, a run's stream is [conv_last of the broadcast block before
+  // it] [its blocks] [conv_first of the broadcast block after it].
   std::vector<std::pair<size_t, std::vector<_Float16>>> run_streams;   // (block index, stream)
+  std::vector<_Float16> head_stream, tail_stream;   // of the run being collected
+  int head_of = -1, tail_of = -1;
   auto flush_run = [&]() {
-    for (auto& rs : run_streams) {
-      BlockPlan& b = e->blocks[rs.first];
-      b.stream_off = add_stream(ar, rs.second, b.nms, Cb);
-      b.stream_bytes = rs.second.size() * 2;
+    if (!run_streams.empty()) {
+      int nms_unused = 0;
+      if (head_of >= 0) {
+        add_stream(ar, head_stream, nms_unused, Cb);
+        BlockPlan& b = e->blocks[run_streams.front().first];
+        b.head_of = head_of;
+        b.head_bytes = head_stream.size() * 2;
+        e->blocks[head_of].last_fused = true;
+      }
+      for (auto& rs : run_streams) {
+        BlockPlan& b = e->blocks[rs.first];
+        b.stream_off = add_stream(ar, rs.second, b.nms, Cb);
+        b.stream_bytes = rs.second.size() * 2;
+      }
+      if (tail_of >= 0) {
+        add_stream(ar, tail_stream, nms_unused, Cb);
+        BlockPlan& b = e->blocks[run_streams.back().first];
+        b.tail_of = tail_of;
+        b.tail_bytes = tail_stream.size() * 2;
+      }
     }
     run_streams.clear();
+    head_of = tail_of = -1;
   };
   for (int i = 0; i < wf.nblocks; ++i) {
     BlockPlan bp;
-    if (wf.is_broadcast(i) || layerwise) flush_run();
+    if (layerwise) flush_run();
     const std::string p = "blocks." + std::to_string(i);
     // conv j of this block, checked against the [k][k][cin][cout] size the packer will read
     auto W = [&](int j, int kw, int cin, int cout) {
@@ -334,6 +365,30 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
                 float v = (ii < kNLoc && j < kNLoc) ? dw.data[(size_t)ii * kNLoc + j] : 0.0f;
                 s1.push_back((_Float16)v);
               }
+      // The run before this block takes conv_first as its tail, the run after it conv_last as its
+      // head (the stand-alone streams below serve P3HIP_NO_BFUSE and broadcast blocks without a
+      // fused neighbour).
+      const bool fused_neighbours = fused && e->bcast_fuse;
+      // fused copies: output pass 1 takes its K slices in the order (1, 0) — slice 1 is the one
+      // still in the act buffer when pass 0 ends (kernels.hip k_block, BC form)
+      std::vector<_Float16> f0, f2;
+      if (fused_neighbours)
+        for (int cp = 0; cp < 2; ++cp)
+          for (int k = 0; k < 2; ++k) {
+            const int ip = cp == 0 ? k : 1 - k;
+            pack_segment(f0, W(0, 1, C, C), 1, 1, C, C, ip * Cb, Cb, cp * Cb, Cb);
+            pack_segment(f2, W(1, 1, C, C), 1, 1, C, C, ip * Cb, Cb, cp * Cb, Cb);
+          }
+      if (fused_neighbours && !run_streams.empty()) {
+        tail_stream = f0;
+        tail_of = i;
+        bp.first_fused = true;
+      }
+      flush_run();
+      if (fused_neighbours && i + 1 < wf.nblocks && !wf.is_broadcast(i + 1)) {
+        head_stream = f2;
+        head_of = i;   // last_fused is set when the run is laid out
+      }
       bp.stream_off = add_stream(ar, s0, bp.nms, CPb);
       bp.stream2_off = add_stream(ar, s1, bp.nms2, 128);
       bp.stream3_off = add_stream(ar, s2, bp.nms3, CPb);
@@ -448,12 +503,29 @@ int grid_for(const p3hip_engine* e, int npos, int npos_per_wg) {
 p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
   p3::BlockArgs a{};
   a.x = e->d_x;
-  a.t = e->d_t;
+  a.t = e->d_s ? e->d_s : e->d_t;
   a.npos = npos;
   a.nblk = count;
-  // the streams of consecutive fused blocks lie back to back in the arena (build_plan)
-  a.wstream = e->d_arena + e->blocks[first].stream_off;
+  // the streams of consecutive fused blocks lie back to back in the arena (build_plan), the fused
+  // broadcast convs' right before the run's first and right after its last block
+  const BlockPlan& fb = e->blocks[first];
+  const BlockPlan& lb = e->blocks[first + count - 1];
   const size_t ms_bytes = (size_t)p3::block_macro_step_bytes(e->wf.C, e->c128_wg8);
+  a.wstream = e->d_arena + fb.stream_off;
+  if (fb.head_of >= 0) {
+    a.head = 1;
+    a.zin = e->d_u;
+    a.wstream = e->d_arena + fb.stream_off - fb.head_bytes;
+    a.nms_total += (int)(fb.head_bytes / ms_bytes);
+  }
+  if (lb.tail_of >= 0) {
+    const BlockPlan& bb = e->blocks[lb.tail_of];
+    a.tail = 1;
+    a.tout = e->d_t;
+    a.tail_scale = e->dev<float>(bb.bn[0].scale_off);
+    a.tail_shift = e->dev<float>(bb.bn[0].shift_off);
+    a.nms_total += (int)(lb.tail_bytes / ms_bytes);
+  }
   for (int b = 0; b < count; ++b) {
     const BlockPlan& bp = e->blocks[first + b];
     a.nms_total += (int)(bp.stream_bytes / ms_bytes);
@@ -496,7 +568,7 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
       c0.in = e->d_x; c0.out16 = e->d_t; c0.npos = npos;
       c0.wstream = e->d_arena + bp.stream_off; c0.nms_total = bp.nms;
       c0.scale = e->dev<float>(bp.bn[0].scale_off); c0.shift = e->dev<float>(bp.bn[0].shift_off);
-      if (!e->check(p3::launch_conv1x1(C, 0, c0, e->n_cu, s), "launch conv_first")) return false;
+      if (!bp.first_fused && !e->check(p3::launch_conv1x1(C, 0, c0, e->n_cu, s), "launch conv_first")) return false;
       p3::BDenseArgs d{};
       d.t = e->d_t; d.u = e->d_u; d.npos = npos;
       d.wstream = e->d_arena + bp.stream2_off; d.nms_total = bp.nms2;
@@ -506,7 +578,7 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
       p3::Conv1x1Args c1{};
       c1.in = e->d_u; c1.out16 = e->d_x; c1.npos = npos;
       c1.wstream = e->d_arena + bp.stream3_off; c1.nms_total = bp.nms3;
-      if (!e->check(p3::launch_conv1x1(C, 1, c1, e->n_cu, s), "launch conv_last")) return false;
+      if (!bp.last_fused && !e->check(p3::launch_conv1x1(C, 1, c1, e->n_cu, s), "launch conv_last")) return false;
     } else if (bp.kind == 4) {
       const size_t half = (size_t)e->batch * wf.Cb * kNLoc;   // elements of one C_b-channel tensor
       _Float16* bufs[5] = {e->d_x, e->d_t, e->d_t + half, e->d_u, e->d_u + half};
@@ -573,6 +645,7 @@ p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version
   e->device = device_ordinal;
   e->flags = flags;
   e->c128_wg8 = getenv("P3HIP_C128_WG8") != nullptr;
+  e->bcast_fuse = getenv("P3HIP_NO_BFUSE") == nullptr;
   auto fail = [&](const std::string& m) {
     g_create_error = m;
     p3hip_destroy(e);
@@ -605,6 +678,7 @@ p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version
             e->check(hipMalloc((void**)&e->d_x, B * C * kNLoc * 2), "hipMalloc x") &&
             e->check(hipMalloc((void**)&e->d_t, B * C * kNLoc * 2), "hipMalloc t") &&
             e->check(hipMalloc((void**)&e->d_u, B * C * kNLoc * 2), "hipMalloc u") &&
+            (e->wf.btype != 1 || e->check(hipMalloc((void**)&e->d_s, B * e->wf.Cb * kNLoc * 2), "hipMalloc s")) &&
             e->check(hipMalloc((void**)&e->d_hp, B * 96 * kNLoc * 4), "hipMalloc hp") &&
             e->check(hipMalloc((void**)&e->d_out, B * p3::kOutStride * 4), "hipMalloc out");
   if (!ok) return fail(e->err);
@@ -619,7 +693,7 @@ void p3hip_destroy(p3hip_engine* e) {
   if (!e) return;
   if (e->stream || e->d_arena) (void)hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->d_arena); hipFree(e->d_feats); hipFree(e->d_x); hipFree(e->d_t); hipFree(e->d_u);
+  hipFree(e->d_arena); hipFree(e->d_feats); hipFree(e->d_x); hipFree(e->d_t); hipFree(e->d_u); hipFree(e->d_s);
   hipFree(e->d_hp); hipFree(e->d_out);
   if (e->h_feats) hipHostFree(e->h_feats);
   if (e->h_feats_compact) hipHostFree(e->h_feats_compact);
@@ -777,8 +851,13 @@ double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
   // every conv the block kernel executes: the inner 3x3s plus the 1x1 reduce and expand
   // a launch covers `nfused / launches-per-forward` blocks on average
   const double blocks_per_launch = launches ? (double)nfused * iters / launches : 1.0;
+  // plus the broadcast blocks' C -> C convs that ride in the block launches
+  int nbconv = 0;
+  for (const BlockPlan& b : e->blocks) nbconv += (b.head_of >= 0) + (b.tail_of >= 0);
+  const double bconv_per_launch = launches ? (double)nbconv * iters / launches : 0.0;
   if (flops_per_launch)
-    *flops_per_launch = blocks_per_launch * 2.0 * n_positions * kNLoc * (n3 * 9.0 * wf.Cb * wf.Cb + 2.0 * wf.C * wf.Cb);
+    *flops_per_launch = 2.0 * n_positions * kNLoc *
+                        (blocks_per_launch * (n3 * 9.0 * wf.Cb * wf.Cb + 2.0 * wf.C * wf.Cb) + bconv_per_launch * (double)wf.C * wf.C);
   if (kernel_name) *kernel_name = p3::block_kernel_name(wf.C, bp->kind, wf.inner);
   return launches ? total_ms / launches : -1.0;
 }

@@ -40,6 +40,15 @@ struct BlockArgs {
   const void* wstream;  // the packed weight streams of the launch's blocks, back to back
   int nms_total;        // their total length in macro-steps (the ring walks them circularly)
   BlockParams blk[kMaxFuse];
+  // The 1x1 convs of the broadcast blocks next to the run ride in the same launch (k_block's BC
+  // form): `head` = conv_last of the broadcast block BEFORE the run (x += W . zin, zin = k_bdense's
+  // output, its stream first in wstream), `tail` = conv_first of the broadcast block AFTER it
+  // (tout = mish(W . mish(bn0(x))), bn0 = tail_scale/shift, its stream last in wstream).
+  int head, tail;
+  const _Float16* zin;
+  _Float16* tout;
+  const float* tail_scale;
+  const float* tail_shift;
 };
 
 struct InitArgs {

@@ -44,7 +44,19 @@ namespace p3 {
 // side in the act buffer).  NW = 4 (C = 128 only): a 256-thread workgroup per position with
 // K = 32 ring steps — 60.6 KB of activations + 12 KB of ring, so TWO workgroups share a CU and one
 // workgroup's BN + mish / store phases run under the other's MFMA phases.
-template <int C, int CB, int KIND, int L, int NW = 8>
+//
+// BC form: the 1x1 convs of the broadcast blocks on either side of the run are taken into the launch
+// (BroadcastResidualBlock, model.py:570-606: x + conv_last(mish(bn1(dense(mish(conv_first(mish(bn0(x)))))))),
+// k_bdense stays its own launch between two block launches):
+//   head: x += W_last . z, z = k_bdense's output (already activated).  A C -> C conv is two output
+//         passes of the expand's shape over two K slices staged from HBM in the accumulator-quad
+//         layout; pass 1's epilogue leaves A1 = mish(bn0(x')) for the first block, A0 is re-made from
+//         the half pass 0 just stored (holding it across pass 1 would not fit the registers).
+//   tail: t = mish(W_first . mish(bn0_b(x'))): two output passes of the reduce's shape.  Pass 0 takes
+//         A0 / A1 from the last block's expand epilogue like any next block; pass 1 re-reads x' as a
+//         position's first block does.
+// Each removes a launch that moved x through HBM twice (k_conv1x1) and the first block's own read.
+template <int C, int CB, int KIND, int L, int NW = 8, bool BC = false>
 __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
   static_assert(NW == 8 || (NW == 4 && CB == 64), "4-wave workgroups: one 64-channel position each");
   constexpr int NPOS = NW == 8 ? 128 / CB : 1;
@@ -63,10 +75,67 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
   int npos_done = 0;
   for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS, ++npos_done) {
     EpiOut16<NT> A1;   // activated reduce input, channel half 1, made by the previous block's expand
+    const bool head = BC && a.head, tail = BC && a.tail;
+    if (head) {
+      // ---- conv_last of the broadcast block before the run: x' = x + W . z ----------------------
+      // Both K slices of z are requested together (one exposed latency).  Pass 0 runs slice 0 then
+      // slice 1, pass 1 starts on slice 1 — still in the act buffer — while slice 0 comes back from
+      // L2 under it (the fused stream packs pass 1's K slices in that order, engine.cpp).
+      f32x4 acc[4][NT];
+      ResRegs16<NT> rr;
+      EpiOut16<NT> S;
+      {
+        ResRegs16<NT> z0;
+        residual_addr16<G, CB, NT>(z0, C, pos0, a.npos, 0);
+        residual_load16<NT>(z0, a.zin);
+        residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, CB);
+        residual_load16<NT>(rr, a.zin);
+        stash16<NT>(S, z0);
+        unstash16<NT>(S);
+        lds_barrier();   // the act buffer is free: every wave is past the previous position's last segment
+        epilogue_write16<G, CB, NT>(smem, S, 0);
+        stash16<NT>(S, rr);   // slice 1 waits raw across the first segment
+      }
+      ring_note_inflight(ring, 12);
+      acc16_zero<NT>(acc);
+      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      unstash16<NT>(S);
+      lds_barrier();
+      epilogue_write16<G, CB, NT>(smem, S, 0);
+      residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, 0);
+      residual_load16<NT>(rr, a.x);
+      ring_note_inflight(ring, 12);
+      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, false, a.blk[0].scale[0], a.blk[0].shift[0], 0);
+      residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, 0);
+      residual_load16<NT>(rr, a.zin);
+      stash16<NT>(S, rr);
+      ring_note_inflight(ring, 12);
+      acc16_zero<NT>(acc);
+      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      unstash16<NT>(S);
+      lds_barrier();
+      epilogue_write16<G, CB, NT>(smem, S, 0);
+      residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, CB);
+      residual_load16<NT>(rr, a.x);
+      ring_note_inflight(ring, 12);
+      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, true, a.blk[0].scale[0], a.blk[0].shift[0], CB);
+      {
+        // half 0 of x' again (the lanes that stored it read it back), activated for the first block
+        ResRegs16<NT> xin;
+        EpiOut16<NT> A0;
+        residual_addr16<G, CB, NT>(xin, C, pos0, a.npos, 0);
+        residual_load16<NT>(xin, a.x);
+        activate_loaded16<G, CB, NT>(A0, xin, a.blk[0].scale[0], a.blk[0].shift[0], 0);
+        lds_barrier();
+        epilogue_write16<G, CB, NT>(smem, A0, 0);
+      }
+    }
 #pragma unroll 1
     for (int blk = 0; blk < a.nblk; ++blk) {
       const BlockParams& bp = a.blk[blk];
-      const bool from_hbm = blk == 0;
+      const bool from_hbm = blk == 0 && !head;
       const bool last = blk + 1 == a.nblk;
       f32x4 acc[4][NT];
       // ---- reduce 1x1 (C -> CB): the act buffer is free here (barrier at the end of the
@@ -89,7 +158,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       // the glds the next two acquires wait for: the 12 residual loads and 12 stores of the
       // previous block's last pass (any block but the launch's very first), and the two halves
       // of x (24 loads) in a position's first block
-      ring_note_inflight(ring, from_hbm ? (npos_done == 0 ? 24 : 48) : 24);
+      // (after a fused tail the previous position ended with 12 stores only: 36)
+      ring_note_inflight(ring, from_hbm ? (npos_done == 0 ? 24 : (tail ? 36 : 48)) : 24);
       acc16_zero<NT>(acc);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
       if (from_hbm) activate_stashed16<G, CB, NT>(A1, bp.scale[0], bp.shift[0], CB);
@@ -133,8 +203,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       // block) the next block's activated reduce input.  Pass 0's residual is requested before
       // its K loop; pass 1's only after its K loop — A0 occupies those registers meanwhile —
       // and lands under the barrier that follows -------------------------------------------------
-      const float* nsc = last ? bp.scale[0] : a.blk[blk + 1].scale[0];
-      const float* nsh = last ? bp.shift[0] : a.blk[blk + 1].shift[0];
+      const bool act_next = !last || tail;
+      const float* nsc = last ? (tail ? a.tail_scale : bp.scale[0]) : a.blk[blk + 1].scale[0];
+      const float* nsh = last ? (tail ? a.tail_shift : bp.shift[0]) : a.blk[blk + 1].shift[0];
       {
         ResRegs16<NT> rr;
         EpiOut16<NT> A0;
@@ -143,16 +214,47 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
         ring_note_inflight(ring, 12);
         acc16_zero<NT>(acc);
         conv_segment16<G, CB, 1, 1>(ring, smem, acc);
-        epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A0, !last, nsc, nsh, 0);
+        epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A0, act_next, nsc, nsh, 0);
         ring_note_inflight(ring, 12);   // pass 0's stores
         acc16_zero<NT>(acc);
         conv_segment16<G, CB, 1, 1>(ring, smem, acc);
         residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, CB);
         residual_load16<NT>(rr, a.x);
         lds_barrier();   // every wave is done with the act buffer
-        if (!last) epilogue_write16<G, CB, NT>(smem, A0, 0);   // the next block's reduce input, half 0
-        epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, !last, nsc, nsh, CB);
+        if (act_next) epilogue_write16<G, CB, NT>(smem, A0, 0);   // the next block's reduce input, half 0
+        epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, act_next, nsc, nsh, CB);
       }
+    }
+    if (tail) {
+      // ---- conv_first of the broadcast block after the run: t = mish(W . mish(bn0_b(x'))) --------
+      // pass 0: half 0 is in the act buffer, half 1 in A1, as for any next block.  Pass 1 starts on
+      // half 1 — still in the act buffer — while half 0 of x' is re-fetched (L2) and activated again.
+      f32x4 acc[4][NT];
+      ResRegs16<NT> tr;
+      ring_note_inflight(ring, 24);   // the last expand pass's 12 residual loads and 12 stores
+      acc16_zero<NT>(acc);
+      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      lds_barrier();
+      epilogue_write16<G, CB, NT>(smem, A1, 0);
+      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      residual_addr16<G, CB, NT>(tr, C, pos0, a.npos, 0);
+      epilogue_store16_mish<NT>(acc, tr, a.tout);
+      {
+        ResRegs16<NT> xin;
+        residual_addr16<G, CB, NT>(xin, C, pos0, a.npos, 0);
+        residual_load16<NT>(xin, a.x);
+        stash16<NT>(A1, xin);
+      }
+      ring_note_inflight(ring, 12);
+      acc16_zero<NT>(acc);
+      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      activate_stashed16<G, CB, NT>(A1, a.tail_scale, a.tail_shift, 0);
+      lds_barrier();
+      epilogue_write16<G, CB, NT>(smem, A1, 0);
+      conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      lds_barrier();   // the act buffer is free for the next position
+      residual_addr16<G, CB, NT>(tr, C, pos0, a.npos, CB);
+      epilogue_store16_mish<NT>(acc, tr, a.tout);
     }
   }
   ring_drain();
@@ -889,21 +991,26 @@ __global__ void __launch_bounds__(1024) k_heads(HeadsArgs a) {
 // =======================================================================================
 // Host-side launchers
 // =======================================================================================
-template <int C, int CB, int KIND, int L, int NW>
-static hipError_t launch_block_t(const BlockArgs& a, int n_cu, hipStream_t s) {
+template <int C, int CB, int KIND, int L, int NW, bool BC>
+static hipError_t launch_block_bc(const BlockArgs& a, int n_cu, hipStream_t s) {
   constexpr int NPOS = NW == 8 ? 128 / CB : 1;
   using G = Geo<NPOS, CB, 3, NW, NW == 8 ? kKMS : 2>;
   constexpr size_t lds = G::ACT_BYTES + ring_bytes(CB, G::KMS);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_block<C, CB, KIND, L, NW>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_block<C, CB, KIND, L, NW, BC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int groups = (a.npos + NPOS - 1) / NPOS, cap = NW == 8 ? n_cu : 2 * n_cu;   // NW = 4: two workgroups per CU
-  hipLaunchKernelGGL((k_block<C, CB, KIND, L, NW>), dim3(groups < cap ? groups : cap), dim3(NW * 64), lds, s, a);
+  hipLaunchKernelGGL((k_block<C, CB, KIND, L, NW, BC>), dim3(groups < cap ? groups : cap), dim3(NW * 64), lds, s, a);
   return hipGetLastError();
+}
+template <int C, int CB, int KIND, int L, int NW>
+static hipError_t launch_block_t(const BlockArgs& a, int n_cu, hipStream_t s) {
+  if (a.head || a.tail) return launch_block_bc<C, CB, KIND, L, NW, true>(a, n_cu, s);
+  return launch_block_bc<C, CB, KIND, L, NW, false>(a, n_cu, s);
 }
 
 // bytes of one ring macro-step of the block kernel that launch_block picks for width C

@@ -79,6 +79,10 @@ CONFIGS: Dict[str, NetConfig] = {
         NetConfig("test_b3c384btl3", 3, 384, 192, 32, 80, 3, 3, "btl"),
         NetConfig("test_b3c384nbt", 3, 384, 192, 32, 64, 3, 2, "nbt"),
         NetConfig("test_b3c192classic", 3, 192, 64, 32, 80, 3, 2, "classic"),
+        # broadcast blocks in the MIDDLE of the trunk (interval 2: blocks 1 and 3), so that block
+        # launches with a broadcast block before them, after them and on both sides all occur
+        NetConfig("test_b5c256nbt_i2", 5, 256, 128, 32, 48, 2, 2, "nbt"),
+        NetConfig("test_b5c128btl1_i2", 5, 128, 64, 32, 32, 2, 1, "btl"),
     ]
 }
 

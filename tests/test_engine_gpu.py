@@ -37,7 +37,7 @@ PEAK_KL_TOL = 2e-4
 # the last six are full-size BASELINE architectures: C1 b8c128nbt, C2 b12c128btl3, C3/C4
 # b12c256btl3 (32 wide positions + a peaked-policy set), C5 b10c384nbt / b14c384btl3
 NETS = ["test_b3c128btl2", "test_b3c128nbt", "test_b3c256btl1", "test_b3c256nbt", "test_b3c384btl3", "test_b3c384nbt",
-        "test_b3c192classic", "b8c128nbt", "b12c128btl3", "b12c256btl3", "b12c256btl3_peaked", "b10c384nbt",
+        "test_b3c192classic", "test_b5c256nbt_i2", "test_b5c128btl1_i2", "b8c128nbt", "b12c128btl3", "b12c256btl3", "b12c256btl3_peaked", "b10c384nbt",
         "b14c384btl3"]
 PROB_KEYS = ("move_probs", "value_probs", "score_probs", "opt_move_probs")
 
@@ -291,6 +291,53 @@ def test_fused_block_launches_equal_one_launch_per_block(built):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout)
     assert outs[0] == outs[1] and outs[0].count("\n") == 3
+
+
+_BFUSE_CHILD = r"""
+import sys, tempfile, os
+sys.path.insert(0, %r)
+import numpy as np
+from p3achygo_amd import engine, features, netspec
+out = {}
+for name, batch in (("b12c256btl3", 300), ("test_b5c256nbt_i2", 5), ("b12c128btl3", 70), ("b8c128nbt", 600)):
+    cfg = netspec.CONFIGS[name]
+    path = os.path.join(tempfile.mkdtemp(), "n.p3w")
+    netspec.save_p3w(path, cfg, netspec.generate_weights(cfg, randomize=True))
+    pos = features.random_positions(batch, seed=5, n_games=9)
+    eng = engine.HipEngine(path, batch)
+    eng.load_all(pos); eng.RunInference()
+    out[name] = np.stack([eng.get_raw(i) for i in range(batch)])
+    eng.close()
+np.savez(sys.argv[1], **out)
+"""
+
+
+@pytest.mark.gpu
+def test_broadcast_convs_inside_block_launches_match_their_own_launches(built, tmp_path):
+    """The broadcast blocks' conv_first / conv_last ride at the tail / head of the neighbouring
+    k_block launches (kernels.hip, BC form).  Same weights and operand precision as the stand-alone
+    k_conv1x1 launches (P3HIP_NO_BFUSE), different MFMA shape and summation order, so fp16 roundings of
+    the intermediates fall differently: the two outputs (each within LOGIT_TOL of the float64 oracle in
+    the parity tests above) stay within LOGIT_TOL of each other — an indexing or weight-order slip
+    would show as O(1) — for one and several positions per workgroup, btl and nbt blocks, both C = 128
+    workgroup forms."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for label, extra in (("fused", {}), ("own", {"P3HIP_NO_BFUSE": "1"}), ("fused_wg8", {"P3HIP_C128_WG8": "1"})):
+        env = dict(os.environ)
+        for k in ("P3HIP_NO_BFUSE", "P3HIP_C128_WG8", "P3HIP_NO_FUSE"):
+            env.pop(k, None)
+        env.update(extra)
+        path = str(tmp_path / (label + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _BFUSE_CHILD % root, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[label] = np.load(path)
+    for name in res["own"].files:
+        a, b, c = res["fused"][name], res["own"][name], res["fused_wg8"][name]
+        assert not np.isnan(a).any() and not np.isnan(c).any()
+        assert np.abs(a[:, :1889] - b[:, :1889]).max() <= LOGIT_TOL, name
+        assert np.abs(c[:, :1889] - b[:, :1889]).max() <= LOGIT_TOL, name
 
 
 @pytest.mark.gpu

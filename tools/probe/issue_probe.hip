@@ -36,8 +36,18 @@ __global__ void __launch_bounds__(512, 1) probe(Out* out, const char* roles, int
   const char role = roles[w];
   if (role == '-') return;
   h8 fa[4], fb[6];
+  if (seed < 0.f) {   // random mantissas: values uniform in [-1, 1) from an integer hash (what trained weights / activations toggle)
+    auto rnd = [&](unsigned k) {
+      unsigned h = (threadIdx.x * 2654435761u) ^ (k * 40503u + 0x9e3779b9u);
+      h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+      return (_Float16)((float)(int)(h & 0xffff) / 32768.0f - 1.0f);
+    };
+    for (int a = 0; a < 4; ++a) for (int e = 0; e < 8; ++e) fa[a][e] = rnd(a * 8 + e);
+    for (int a = 0; a < 6; ++a) for (int e = 0; e < 8; ++e) fb[a][e] = rnd(100 + a * 8 + e);
+  } else {
   for (int a = 0; a < 4; ++a) for (int e = 0; e < 8; ++e) fa[a][e] = (_Float16)(seed * (threadIdx.x % 7 + a + e) - seed * 3);
   for (int a = 0; a < 6; ++a) for (int e = 0; e < 8; ++e) fb[a][e] = (_Float16)(seed * (threadIdx.x % 5 + a * e) - seed * 5);
+  }
   f32x4 acc[4][6];
   for (int a = 0; a < 4; ++a) for (int b = 0; b < 6; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
   f32x2 v[8];
@@ -111,8 +121,8 @@ void run(const char* roles, int iters_m, int iters_v, float seed, const char* la
 }
 
 int main() {
-  const int im = 6000, iv = 60000;
-  for (float seed : {0.0f, 0.37f}) {
+  const int im = 30000, iv = 60000;
+  for (float seed : {0.0f, 0.37f, -1.0f}) {
     run<0>("MMMMMMMM", im, iv, seed, "MFMA on both waves of a SIMD");
     run<0>("MMMM----", 2 * im, iv, seed, "MFMA on one wave per SIMD");
     run<0>("VVVVVVVV", im, iv, seed, "VALU on both waves");

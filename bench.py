@@ -35,7 +35,7 @@ import numpy as np  # noqa: E402
 
 MODEL = "b12c256btl3"
 BATCH = 1024
-GROUPS = 4          # game groups per GPU: 3 forward passes queued while the 4th group is on the host
+DEFAULT_GROUPS = GROUPS = 4          # game groups per GPU: 3 forward passes queued while the 4th group is on the host
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 PF
 LADDER_BUDGET = 0       # ladder read-out work bound of the host: 0 = the reference's exact read-out (default)
 
@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4096, help="timed engine batches (p3hip_run calls) per GPU")
     ap.add_argument("--warmup", type=int, default=16, help="untimed warm-up rounds (one batch per game group each)")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--groups", type=int, default=DEFAULT_GROUPS, help="game groups (engine instances / HIP streams) per GPU")
     ap.add_argument("--model", default=MODEL)
     ap.add_argument("--engine-steps", type=int, default=200, help="timed steps of the engine-only leg")
     ap.add_argument("--ladder-budget", type=int, default=LADDER_BUDGET,
@@ -151,6 +152,7 @@ def main():
 
     # ---- headline: self-play through the C ABI ----------------------------------------------
     threads = max(2, min(16, len(cpus)))
+    GROUPS = args.groups   # local from here on
     steps = ((args.steps + GROUPS - 1) // GROUPS) * GROUPS     # whole rounds
     host_api.set_groups(GROUPS)
     host_api.set_ladder_budget(args.ladder_budget)

@@ -79,7 +79,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // kernel column kx, the odd 16-row tile and the k32 index inside the tap are immediates.
 // Body = one kernel row (KW taps), runtime loop over ky.
 template <class G, int COUT_PASS, int KW, int NTAPS_PAD, int NTn = 0>
-__device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS, G::KMS), G::NW>& ring, char* smem,
+__device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS, G::KMS), G::NW, G::RD>& ring, char* smem,
                                                f32x4 (&acc)[4][NTn]) {
   using T = Tiling16<G, COUT_PASS>;
   static_assert(NTn == T::NT, "accumulator shape");
@@ -183,7 +183,7 @@ __device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS, G
 // activation reloads issued after the previous step's last weight read must have landed — the
 // fragments a step uses are all older than that.
 template <class G, int COUT_PASS, int NTn = 0>
-__device__ __forceinline__ void conv_segment16_3x3(Ring<ring_slot_bytes(COUT_PASS, G::KMS), G::NW>& ring, char* smem,
+__device__ __forceinline__ void conv_segment16_3x3(Ring<ring_slot_bytes(COUT_PASS, G::KMS), G::NW, G::RD>& ring, char* smem,
                                                    f32x4 (&acc)[4][NTn]) {
   using T = Tiling16<G, COUT_PASS>;
   static_assert(NTn == T::NT && T::NT == 6 && G::CB % 32 == 0, "shape");

@@ -38,19 +38,24 @@ constexpr int kBL = 19;
 constexpr int kKMS = 4;           // k16-steps (K = 64) per ring macro-step
 constexpr int kRingSlots = 3;     // R
 constexpr int kRingDepth = 2;     // D = R - 1 (see ring_acquire)
+#ifndef P3_RING_DEPTH4
+#define P3_RING_DEPTH4 2
+#endif
+constexpr int kRingDepth4 = P3_RING_DEPTH4;   // ring depth of the 4-wave block kernel (K = 32 steps): 3 and 4 measure the same as 2 (gpurun_out/ringdepth_ab.log)
 // bytes of one macro-step for a COUT_PASS-wide weight panel: `kms` blocks of [2][CP][8] fp16
 constexpr int ring_slot_bytes(int cout_pass, int kms = kKMS) { return kms * cout_pass * 32; }
-constexpr int ring_bytes(int cout_pass, int kms = kKMS) { return kRingSlots * ring_slot_bytes(cout_pass, kms); }
+constexpr int ring_bytes(int cout_pass, int kms = kKMS, int depth = kRingDepth) { return (depth + 1) * ring_slot_bytes(cout_pass, kms); }
 
 // ---------------------------------------------------------------------------------------
 // Geometry of one conv "space": NPOS positions, NT_TOTAL 32-wide location tiles each.
 // NW = waves per workgroup (8; 4 for the two-workgroups-per-CU form of the C = 128 block kernel),
-// KMS = k16 steps per ring macro-step.
-template <int NPOS_, int CB_, int KW_, int NW_ = 8, int KMS_ = kKMS>
+// KMS = k16 steps per ring macro-step, RD = macro-steps the weight ring prefetches ahead (RD + 1 slots).
+template <int NPOS_, int CB_, int KW_, int NW_ = 8, int KMS_ = kKMS, int RD_ = kRingDepth>
 struct Geo {
   static constexpr int NPOS = NPOS_;
   static constexpr int NW = NW_;
   static constexpr int KMS = KMS_;
+  static constexpr int RD = RD_;
   static constexpr int CB = CB_;                 // channels resident in the act buffer
   static constexpr int NCH = CB / 8;             // 16-byte chunks per slot
   // bytes per slot: the channels plus one 16-byte pad.  The slot stride is then an odd
@@ -119,8 +124,9 @@ __device__ __forceinline__ h4 bn_mish4(f32x4 v, f32x4 sc, f32x4 sh) {
 // Weight ring.  RS = bytes per macro-step (16 KiB for 128-wide panels, 8 KiB for 64-wide, 4 KiB
 // for the 4-wave kernel's K = 32 steps); each of the NW waves copies RS/NW bytes (G = RS/NW/1024
 // glds of 1 KiB) per macro-step.
-template <int RS, int NW = 8>
+template <int RS, int NW = 8, int D = kRingDepth>
 struct Ring {
+  static constexpr int DEPTH = D, SLOTS = D + 1;
   static constexpr int G = RS / (NW * 1024);
   static constexpr int PIECE = RS / NW;
   static_assert((G == 1 || G == 2) && G * NW * 1024 == RS, "ring slot size");
@@ -132,8 +138,8 @@ struct Ring {
   const char* gcur;    // this wave's piece of the next macro-step to prefetch (lane offset excluded)
   const char* gbeg;    // ... of macro-step 0
   const char* gend;    // ... one past the last macro-step (the stream is circular)
-  uint32_t fill[kRingSlots];  // LDS address of this wave's piece in the slot the next, next+1, ... prefetch fills
-  uint32_t use[kRingSlots];   // LDS offset of the slot the next, next+1, ... acquire returns
+  uint32_t fill[D + 1];  // LDS address of this wave's piece in the slot the next, next+1, ... prefetch fills
+  uint32_t use[D + 1];   // LDS offset of the slot the next, next+1, ... acquire returns
   uint32_t lds_base;   // byte offset of the ring inside the dynamic LDS array
   int tol;             // acquires left that must tolerate `extra` younger register loads/stores
   int extra;           // 12, 24, 36 or 48 (see ring_note_inflight)
@@ -151,13 +157,13 @@ __device__ __forceinline__ void rotate_left(uint32_t (&v)[N]) {
   v[N - 1] = t;
 }
 
-template <int RS, int NW>
-__device__ __forceinline__ void ring_issue(Ring<RS, NW>& r, char* smem) {
+template <int RS, int NW, int D>
+__device__ __forceinline__ void ring_issue(Ring<RS, NW, D>& r, char* smem) {
   const uint32_t lane16 = (threadIdx.x & 63) * 16;
   const char* gp = r.gcur + lane16;      // uniform base + 32-bit lane offset
   char* lp = smem + r.fill[0];
 #pragma unroll
-  for (int i = 0; i < Ring<RS, NW>::G; ++i)
+  for (int i = 0; i < Ring<RS, NW, D>::G; ++i)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + i * 1024),
                                      (__attribute__((address_space(3))) void*)(lp + i * 1024), 16, 0, 0);
   r.gcur += RS;
@@ -165,8 +171,8 @@ __device__ __forceinline__ void ring_issue(Ring<RS, NW>& r, char* smem) {
   rotate_left(r.fill);
 }
 
-template <int RS, int NW>
-__device__ __forceinline__ void ring_init(Ring<RS, NW>& r, char* smem, const void* gbase,
+template <int RS, int NW, int D>
+__device__ __forceinline__ void ring_init(Ring<RS, NW, D>& r, char* smem, const void* gbase,
                                           int nms_total, uint32_t lds_base) {
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   r.gbeg = (const char*)gbase + wid * (RS / NW);
@@ -174,13 +180,13 @@ __device__ __forceinline__ void ring_init(Ring<RS, NW>& r, char* smem, const voi
   r.gcur = r.gbeg;
   r.lds_base = lds_base;
 #pragma unroll
-  for (int i = 0; i < kRingSlots; ++i) {
+  for (int i = 0; i < D + 1; ++i) {
     r.use[i] = lds_base + i * RS;
     r.fill[i] = lds_base + i * RS + wid * (RS / NW);
   }
   r.tol = 0;
   r.extra = 0;
-  for (int i = 0; i < kRingDepth; ++i) ring_issue(r, smem);
+  for (int i = 0; i < D; ++i) ring_issue(r, smem);
 }
 
 // Makes the next macro-step readable and returns its LDS byte offset.
@@ -200,28 +206,19 @@ __device__ __forceinline__ void ring_init(Ring<RS, NW>& r, char* smem, const voi
 // the first acquire of a segment (it doubles as the "previous layer written" barrier); a
 // K loop that knows how many reads it issued after the last fragment read of the macro-step
 // being recycled passes that count instead and does not stall on its own recent reads.
-template <int LGKM = 0, int RS = 0, int NW = 8>
-__device__ __forceinline__ uint32_t ring_acquire(Ring<RS, NW>& r, char* smem) {
-  static_assert(kRingDepth == 2 && kXLoads == 12, "vmcnt immediates below");
-  constexpr int G = Ring<RS, NW>::G;  // base immediate (D-1)*G = G
+template <int LGKM = 0, int RS = 0, int NW = 8, int D = kRingDepth>
+__device__ __forceinline__ uint32_t ring_acquire(Ring<RS, NW, D>& r, char* smem) {
+  static_assert(kXLoads == 12, "vmcnt immediates below");
+  constexpr int B = (D - 1) * Ring<RS, NW, D>::G;   // glds of the younger macro-steps that may stay in flight
+  static_assert(B + 48 <= 63, "vmcnt is a 6-bit count");
   if (r.tol > 0) {
     r.tol--;
-    if (r.extra == 12) {
-      if (G == 2) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
-      else asm volatile("s_waitcnt vmcnt(13) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
-    } else if (r.extra == 24) {
-      if (G == 2) asm volatile("s_waitcnt vmcnt(26) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
-      else asm volatile("s_waitcnt vmcnt(25) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
-    } else if (r.extra == 36) {
-      if (G == 2) asm volatile("s_waitcnt vmcnt(38) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
-      else asm volatile("s_waitcnt vmcnt(37) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
-    } else {
-      if (G == 2) asm volatile("s_waitcnt vmcnt(50) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
-      else asm volatile("s_waitcnt vmcnt(49) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
-    }
+    if (r.extra == 12) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"(B + 12), "n"(LGKM) : "memory");
+    else if (r.extra == 24) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"(B + 24), "n"(LGKM) : "memory");
+    else if (r.extra == 36) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"(B + 36), "n"(LGKM) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"(B + 48), "n"(LGKM) : "memory");
   } else {
-    if (G == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
-    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(%0)" ::"n"(LGKM) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"(B), "n"(LGKM) : "memory");
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -234,13 +231,13 @@ __device__ __forceinline__ uint32_t ring_acquire(Ring<RS, NW>& r, char* smem) {
 // Call right after issuing `extra` (12, 24, 36 or 48) ordinary vector-memory operations whose
 // completion should not be forced by the next D ring acquires (and nothing else since the
 // last ring_issue): the glds those acquires wait for are older than all of them.
-template <int RS, int NW>
-__device__ __forceinline__ void ring_note_inflight(Ring<RS, NW>& r, int extra) {
-  r.tol = kRingDepth;
+template <int RS, int NW, int D>
+__device__ __forceinline__ void ring_note_inflight(Ring<RS, NW, D>& r, int extra) {
+  r.tol = D;
   r.extra = extra;
 }
-template <int RS, int NW>
-__device__ __forceinline__ void ring_note_xloads(Ring<RS, NW>& r) { ring_note_inflight(r, kXLoads); }
+template <int RS, int NW, int D>
+__device__ __forceinline__ void ring_note_xloads(Ring<RS, NW, D>& r) { ring_note_inflight(r, kXLoads); }
 
 __device__ __forceinline__ void ring_drain() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -317,7 +314,7 @@ __device__ __forceinline__ void wait_lgkm_n(int n) {
 // SWAP: issue mfma(act fragment, weight fragment) instead, i.e. D[act row][weight row]: a lane
 // then holds 4 consecutive ACT rows for one weight row (k_bdense: rows are channels).
 template <class G, int COUT_PASS, int KW, int NTAPS_PAD, bool SWAP = false, int NTn = 0>
-__device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS, G::KMS), G::NW>& ring, char* smem,
+__device__ __forceinline__ void conv_segment(Ring<ring_slot_bytes(COUT_PASS, G::KMS), G::NW, G::RD>& ring, char* smem,
                                              f32x16 (&acc)[2][NTn]) {
   using T = Tiling<G, COUT_PASS>;
   static_assert(NTn == T::NT, "accumulator shape");
@@ -646,7 +643,10 @@ __device__ __forceinline__ void stage_in(char* smem, const _Float16* __restrict_
 
 template <class G>
 __device__ __forceinline__ void act_zero(char* smem) {
-  for (int i = threadIdx.x * 16; i < G::ACT_BYTES; i += G::NW * 64 * 16) *(f32x4*)(smem + i) = f32x4{0, 0, 0, 0};
+  // the zero is made here (opaque to the optimiser): a hoisted zero vector would be carried — spilled —
+  // across the whole kernel for a use inside the position loop
+  const float z = __builtin_bit_cast(float, launder(0));
+  for (int i = threadIdx.x * 16; i < G::ACT_BYTES; i += G::NW * 64 * 16) *(f32x4*)(smem + i) = f32x4{z, z, z, z};
 }
 
 // Epilogue B: out[c][loc] = acc + residual (read from the same place) -> fp16 global, in

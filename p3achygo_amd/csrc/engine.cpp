@@ -226,6 +226,10 @@ struct p3hip_engine {
   unsigned char* h_feats_compact = nullptr;  // pinned, dense
   unsigned char* d_feats = nullptr;
   _Float16 *d_x = nullptr, *d_t = nullptr, *d_u = nullptr;
+#ifdef P3_DIAG
+  unsigned long long* d_stamps = nullptr;   // diagnostic build: k_block phase stamps of one launch (P3DIAG_LAUNCH)
+  int launch_index = 0;
+#endif
   _Float16* d_s = nullptr;   // nbt trunks: the block kernel's inner-stream scratch (t and u carry the broadcast blocks' tensors)
   float* d_hp = nullptr;
   float* d_out = nullptr;
@@ -526,6 +530,16 @@ p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
     a.tail_shift = e->dev<float>(bb.bn[0].shift_off);
     a.nms_total += (int)(lb.tail_bytes / ms_bytes);
   }
+  {
+    // Workgroups run their positions in lockstep, so the HBM-bound phases of a launch (the fused
+    // broadcast convs above all) hit the memory system from every CU at once.  A start-up stagger of
+    // 10,000 cycles per step (seven steps across the CU slots of an XCD) measured -2 % on the forward
+    // pass at four positions per workgroup (gpurun_out/stagger_ab.log); it costs its own length once
+    // per launch, so short launches go without.  P3HIP_STAGGER overrides (0 = off).
+    static const int stagger_env = getenv("P3HIP_STAGGER") ? atoi(getenv("P3HIP_STAGGER")) : -1;
+    const bool long_launch = npos >= 3 * e->n_cu * (e->wf.C == 256 || e->c128_wg8 ? 1 : 2);
+    a.stagger = stagger_env >= 0 ? stagger_env : ((a.head || a.tail) && long_launch ? 10000 : 0);
+  }
   for (int b = 0; b < count; ++b) {
     const BlockPlan& bp = e->blocks[first + b];
     a.nms_total += (int)(bp.stream_bytes / ms_bytes);
@@ -561,6 +575,9 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
     a.game_w = e->dev<float>(e->game_w_off); a.game_b = e->dev<float>(e->game_b_off);
     if (!e->check(p3::launch_init(C, a, grid_for(e, npos, 1), s), "launch k_init")) return false;
   }
+#ifdef P3_DIAG
+  e->launch_index = 0;
+#endif
   for (size_t bi = 0; bi < e->blocks.size(); ++bi) {
     const BlockPlan& bp = e->blocks[bi];
     if (bp.kind == 3) {
@@ -595,6 +612,14 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
     } else {
       const int run = fused_run(e, bi);
       p3::BlockArgs a = block_args(e, bi, run, npos);
+#ifdef P3_DIAG
+      {
+        static const int which = getenv("P3DIAG_LAUNCH") ? atoi(getenv("P3DIAG_LAUNCH")) : 1;
+        constexpr size_t bytes = (size_t)p3::kStampWgs * 8 * p3::kStampSections * p3::kStampSlots * 8;
+        if (!e->d_stamps && hipMalloc((void**)&e->d_stamps, bytes) == hipSuccess) hipMemset(e->d_stamps, 0, bytes);
+        a.stamps = (e->launch_index++ == which) ? e->d_stamps : nullptr;
+      }
+#endif
       const bool timed = e->time_blocks && 2 * e->timed_blocks + 1 < (int)e->blk_ev.size();
       if (timed) hipEventRecord(e->blk_ev[2 * e->timed_blocks], s);
       if (!e->check(p3::launch_block(C, bp.kind, wf.inner, e->c128_wg8, a, e->n_cu, s), "launch k_block")) return false;
@@ -861,5 +886,15 @@ double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
   if (kernel_name) *kernel_name = p3::block_kernel_name(wf.C, bp->kind, wf.inner);
   return launches ? total_ms / launches : -1.0;
 }
+
+#ifdef P3_DIAG
+// diagnostic build only: the phase stamps of the last forward pass's launch P3DIAG_LAUNCH
+int p3hip_debug_block_stamps(p3hip_engine* e, unsigned long long* out, int n) {
+  if (!e->bind() || !e->d_stamps) return 1;
+  constexpr int total = p3::kStampWgs * 8 * p3::kStampSections * p3::kStampSlots;
+  hipStreamSynchronize(e->stream);
+  return hipMemcpy(out, e->d_stamps, (size_t)(n < total ? n : total) * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+#endif
 
 }  // extern "C"

@@ -49,7 +49,19 @@ struct BlockArgs {
   _Float16* tout;
   const float* tail_scale;
   const float* tail_shift;
+  // start-up stagger (shader-clock cycles per step, 0 = none): workgroup b begins (b / 8) % 8 steps late,
+  // so the CUs of an XCD are not all in their HBM-bound phases (head / tail / residual traffic) at once
+  int stagger;
+#ifdef P3_DIAG
+  // diagnostic build only (make diag): lane 0 of every wave of workgroups 0..7 stores s_memtime at
+  // the phase boundaries of its second position: stamps[((wg * 8 + wave) * 8 + section) * 32 + k],
+  // section = block index (0..5), 6 = head, 7 = tail.  Never read by the kernel.
+  unsigned long long* stamps;
+#endif
 };
+#ifdef P3_DIAG
+constexpr int kStampWgs = 8, kStampSections = 8, kStampSlots = 32;
+#endif
 
 struct InitArgs {
   const void* feats;  // npos x p3hip_features (1860 B each)

@@ -56,11 +56,22 @@ namespace p3 {
 //         A0 / A1 from the last block's expand epilogue like any next block; pass 1 re-reads x' as a
 //         position's first block does.
 // Each removes a launch that moved x through HBM twice (k_conv1x1) and the first block's own read.
+#ifdef P3_DIAG
+#define P3_STAMP(section, k)                                                                              \
+  do {                                                                                                    \
+    if (a.stamps && blockIdx.x < kStampWgs && npos_done == 1 && (threadIdx.x & 63) == 0)                 \
+      a.stamps[((blockIdx.x * 8 + (threadIdx.x >> 6)) * kStampSections + (section)) * kStampSlots + (k)] = \
+          __builtin_amdgcn_s_memtime();                                                                   \
+  } while (0)
+#else
+#define P3_STAMP(section, k) do {} while (0)
+#endif
+
 template <int C, int CB, int KIND, int L, int NW = 8, bool BC = false>
 __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
   static_assert(NW == 8 || (NW == 4 && CB == 64), "4-wave workgroups: one 64-channel position each");
   constexpr int NPOS = NW == 8 ? 128 / CB : 1;
-  using G = Geo<NPOS, CB, 3, NW, NW == 8 ? kKMS : 2>;
+  using G = Geo<NPOS, CB, 3, NW, NW == 8 ? kKMS : 2, NW == 8 ? kRingDepth : kRingDepth4>;
   using T = Tiling16<G, CB>;
   constexpr int NT = T::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,7 +79,12 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
   static_assert(C / CB == 2, "two input slices / two output passes");
 
   act_zero<G>(smem);
-  Ring<T::RS, NW> ring;
+  if (BC && a.stagger > 0) {
+    const int key = (blockIdx.x >> 3) & 7;   // consecutive block ids go to different XCDs: this is the CU slot inside one
+    const unsigned long long until = __builtin_amdgcn_s_memtime() + (unsigned long long)key * a.stagger;
+    while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(16);
+  }
+  Ring<T::RS, NW, G::RD> ring;
   ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
   lds_barrier();
 
@@ -84,6 +100,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       f32x4 acc[4][NT];
       ResRegs16<NT> rr;
       EpiOut16<NT> S;
+      P3_STAMP(6, 0);
       {
         ResRegs16<NT> z0;
         residual_addr16<G, CB, NT>(z0, C, pos0, a.npos, 0);
@@ -98,29 +115,39 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       }
       ring_note_inflight(ring, 12);
       acc16_zero<NT>(acc);
+      P3_STAMP(6, 1);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      P3_STAMP(6, 2);
       unstash16<NT>(S);
       lds_barrier();
       epilogue_write16<G, CB, NT>(smem, S, 0);
       residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, 0);
       residual_load16<NT>(rr, a.x);
       ring_note_inflight(ring, 12);
+      P3_STAMP(6, 4);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      P3_STAMP(6, 5);
       epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, false, a.blk[0].scale[0], a.blk[0].shift[0], 0);
+      P3_STAMP(6, 6);
       residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, 0);
       residual_load16<NT>(rr, a.zin);
       stash16<NT>(S, rr);
       ring_note_inflight(ring, 12);
       acc16_zero<NT>(acc);
+      P3_STAMP(6, 7);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      P3_STAMP(6, 8);
       unstash16<NT>(S);
       lds_barrier();
       epilogue_write16<G, CB, NT>(smem, S, 0);
       residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, CB);
       residual_load16<NT>(rr, a.x);
       ring_note_inflight(ring, 12);
+      P3_STAMP(6, 10);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      P3_STAMP(6, 11);
       epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, true, a.blk[0].scale[0], a.blk[0].shift[0], CB);
+      P3_STAMP(6, 12);
       {
         // half 0 of x' again (the lanes that stored it read it back), activated for the first block
         ResRegs16<NT> xin;
@@ -131,6 +158,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
         lds_barrier();
         epilogue_write16<G, CB, NT>(smem, A0, 0);
       }
+      P3_STAMP(6, 13);
     }
 #pragma unroll 1
     for (int blk = 0; blk < a.nblk; ++blk) {
@@ -138,6 +166,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       const bool from_hbm = blk == 0 && !head;
       const bool last = blk + 1 == a.nblk;
       f32x4 acc[4][NT];
+      P3_STAMP(blk, 0);
       // ---- reduce 1x1 (C -> CB): the act buffer is free here (barrier at the end of the
       // previous block / position), half 0 goes in, half 1 follows under the barrier after the
       // first K slice ------------------------------------------------------------------------
@@ -161,17 +190,23 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       // (after a fused tail the previous position ended with 12 stores only: 36)
       ring_note_inflight(ring, from_hbm ? (npos_done == 0 ? 24 : (tail ? 36 : 48)) : 24);
       acc16_zero<NT>(acc);
+      P3_STAMP(blk, 1);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      P3_STAMP(blk, 2);
       if (from_hbm) activate_stashed16<G, CB, NT>(A1, bp.scale[0], bp.shift[0], CB);
       lds_barrier();
       epilogue_write16<G, CB, NT>(smem, A1, 0);
+      P3_STAMP(blk, 3);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      P3_STAMP(blk, 4);
       if (KIND == 0) {
 #pragma unroll
         for (int j = 1; j <= L; ++j) {
           epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[j], bp.shift[j]);
           acc16_zero<NT>(acc);
+          P3_STAMP(blk, 3 + 2 * j);
           conv_segment16_3x3<G, CB>(ring, smem, acc);
+          P3_STAMP(blk, 4 + 2 * j);
         }
         epilogue_layer16<G, CB, NT>(smem, acc, bp.scale[L + 1], bp.shift[L + 1]);
       } else {
@@ -203,6 +238,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       // block) the next block's activated reduce input.  Pass 0's residual is requested before
       // its K loop; pass 1's only after its K loop — A0 occupies those registers meanwhile —
       // and lands under the barrier that follows -------------------------------------------------
+      P3_STAMP(blk, 11);
       const bool act_next = !last || tail;
       const float* nsc = last ? (tail ? a.tail_scale : bp.scale[0]) : a.blk[blk + 1].scale[0];
       const float* nsh = last ? (tail ? a.tail_shift : bp.shift[0]) : a.blk[blk + 1].shift[0];
@@ -213,16 +249,22 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
         residual_load16<NT>(rr, a.x);
         ring_note_inflight(ring, 12);
         acc16_zero<NT>(acc);
+        P3_STAMP(blk, 12);
         conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+        P3_STAMP(blk, 13);
         epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A0, act_next, nsc, nsh, 0);
         ring_note_inflight(ring, 12);   // pass 0's stores
         acc16_zero<NT>(acc);
+        P3_STAMP(blk, 14);
         conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+        P3_STAMP(blk, 15);
         residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, CB);
         residual_load16<NT>(rr, a.x);
         lds_barrier();   // every wave is done with the act buffer
         if (act_next) epilogue_write16<G, CB, NT>(smem, A0, 0);   // the next block's reduce input, half 0
+        P3_STAMP(blk, 16);
         epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, act_next, nsc, nsh, CB);
+        P3_STAMP(blk, 17);
       }
     }
     if (tail) {
@@ -231,14 +273,20 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       // half 1 — still in the act buffer — while half 0 of x' is re-fetched (L2) and activated again.
       f32x4 acc[4][NT];
       ResRegs16<NT> tr;
+      P3_STAMP(7, 0);
       ring_note_inflight(ring, 24);   // the last expand pass's 12 residual loads and 12 stores
       acc16_zero<NT>(acc);
+      P3_STAMP(7, 1);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      P3_STAMP(7, 2);
       lds_barrier();
       epilogue_write16<G, CB, NT>(smem, A1, 0);
+      P3_STAMP(7, 4);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      P3_STAMP(7, 5);
       residual_addr16<G, CB, NT>(tr, C, pos0, a.npos, 0);
       epilogue_store16_mish<NT>(acc, tr, a.tout);
+      P3_STAMP(7, 6);
       {
         ResRegs16<NT> xin;
         residual_addr16<G, CB, NT>(xin, C, pos0, a.npos, 0);
@@ -247,14 +295,19 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       }
       ring_note_inflight(ring, 12);
       acc16_zero<NT>(acc);
+      P3_STAMP(7, 7);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      P3_STAMP(7, 8);
       activate_stashed16<G, CB, NT>(A1, a.tail_scale, a.tail_shift, 0);
       lds_barrier();
       epilogue_write16<G, CB, NT>(smem, A1, 0);
+      P3_STAMP(7, 10);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
+      P3_STAMP(7, 11);
       lds_barrier();   // the act buffer is free for the next position
       residual_addr16<G, CB, NT>(tr, C, pos0, a.npos, CB);
       epilogue_store16_mish<NT>(acc, tr, a.tout);
+      P3_STAMP(7, 12);
     }
   }
   ring_drain();
@@ -569,7 +622,7 @@ constexpr int kTtStride = 784;  // bytes per channel row in LDS: 384 fp16 + 16 B
 
 // Tt seen as a conv act buffer: one slot per channel (128 per pass), K = 384 board points.
 struct GeoTt {
-  static constexpr int NW = 8, KMS = kKMS;
+  static constexpr int NW = 8, KMS = kKMS, RD = kRingDepth;
   static constexpr int NPOS = 1, CB = 384, NCH = 48, SLOTB = kTtStride, PAD = 0, S = 1, NROWS = 128,
                        NT_POS = 4, PADTOP = 0, PSLOTS = 128, ACT_BYTES = 128 * kTtStride, NT_TOTAL = 4;
 };
@@ -994,8 +1047,8 @@ __global__ void __launch_bounds__(1024) k_heads(HeadsArgs a) {
 template <int C, int CB, int KIND, int L, int NW, bool BC>
 static hipError_t launch_block_bc(const BlockArgs& a, int n_cu, hipStream_t s) {
   constexpr int NPOS = NW == 8 ? 128 / CB : 1;
-  using G = Geo<NPOS, CB, 3, NW, NW == 8 ? kKMS : 2>;
-  constexpr size_t lds = G::ACT_BYTES + ring_bytes(CB, G::KMS);
+  using G = Geo<NPOS, CB, 3, NW, NW == 8 ? kKMS : 2, NW == 8 ? kRingDepth : kRingDepth4>;
+  constexpr size_t lds = G::ACT_BYTES + ring_bytes(CB, G::KMS, G::RD);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_block<C, CB, KIND, L, NW, BC>,

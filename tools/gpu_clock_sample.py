@@ -1,6 +1,6 @@
 """Shader clock and socket power while the headline net's forward pass loops (amdsmi samples every
 20 ms from a side thread): random weights, then the same binary on all-zero weights.
-Usage: gpu_clock_sample.py [seconds per leg]"""
+Usage: gpu_clock_sample.py [seconds per leg] [net]"""
 import os, sys, tempfile, threading, time, glob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -49,7 +49,7 @@ smp = Sampler()
 print("sampler:", smp.kind, "idle:", smp.read(), flush=True)
 batch = 1024
 pos = np.tile(features.random_positions(64, seed=1, n_games=16), 16)[:batch].copy()
-cfg = netspec.CONFIGS["b12c256btl3"]
+cfg = netspec.CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "b12c256btl3"]
 for label in ("random", "zeros", "random"):
     W = netspec.generate_weights(cfg)
     if label == "zeros":
@@ -80,7 +80,10 @@ for label in ("random", "zeros", "random"):
     dt = time.perf_counter() - t0
     stop = True; th.join()
     s = np.array(samples[len(samples) // 4:])   # steady state
-    kms, fl, kname = eng.time_trunk_kernel(batch, 20)
+    try:
+        kms, fl, kname = eng.time_trunk_kernel(batch, 20)
+    except Exception:   # layer-wise trunks have no fused block kernel
+        kms, fl, kname = float("nan"), 0.0, "-"
     print(f"{label:7s} forward {dt / n * 1e3:.3f} ms; {kname} {kms:.4f} ms/launch frac {fl / kms / 1e9 / 2500:.3f}; "
           f"gfx clock mean {s[:, 0].mean():.0f} MHz (min {s[:, 0].min():.0f}, max {s[:, 0].max():.0f}); "
           f"socket power mean {s[:, 1].mean():.0f} W (max {s[:, 1].max():.0f}); {len(s)} samples", flush=True)

@@ -102,17 +102,17 @@ __global__ void __launch_bounds__(512, 2) kloop(const h8* __restrict__ w, float*
 }
 
 template <int MODE>
-void run(const char* name, const h8* w, float* out, int steps, int wsteps) {
+void run(const char* name, const h8* w, float* out, int steps, int wsteps, int waves = 8) {
   (void)hipFuncSetAttribute((const void*)kloop<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int rep = 0; rep < 3; ++rep) kloop<MODE><<<256, 512, 131072>>>(w, out, steps, wsteps);
+  for (int rep = 0; rep < 3; ++rep) kloop<MODE><<<256, waves * 64, 131072>>>(w, out, steps, wsteps);
   (void)hipEventRecord(e0);
-  for (int rep = 0; rep < 5; ++rep) kloop<MODE><<<256, 512, 131072>>>(w, out, steps, wsteps);
+  for (int rep = 0; rep < 5; ++rep) kloop<MODE><<<256, waves * 64, 131072>>>(w, out, steps, wsteps);
   (void)hipEventRecord(e1);
   (void)hipDeviceSynchronize();
   float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5;
-  const double flop = 16384.0 * 24 * steps * 8 * 256;
-  printf("%-40s %.3f ms  %.0f TFLOP/s\n", name, ms, flop / ms / 1e9);
+  const double flop = 16384.0 * 24 * steps * waves * 256;
+  printf("%-40s (%d waves/CU) %.3f ms  %.0f TFLOP/s\n", name, waves, ms, flop / ms / 1e9);
 }
 
 // 4 waves per CU (one per SIMD, up to 512 registers each), wave tile 8 x 6: 14 ds_read_b128 per 48 MFMAs.
@@ -186,6 +186,10 @@ int main() {
     run<3>("B from LDS, A from global (2 ahead)", w, out, steps, wsteps);
     run<4>("A+B from LDS + barrier + LDS-DMA ring", w, out, steps, wsteps);
     run<5>("A+B from LDS + barrier + reg-staged ring", w, out, steps, wsteps);
+    // one wave per SIMD with the same 4 x 6 tile: can a single wave keep the MFMA pipe busy?
+    run<0>("MFMA only", w, out, steps, wsteps, 4);
+    run<1>("A+B from LDS", w, out, steps, wsteps, 4);
+    run<3>("B from LDS, A from global (2 ahead)", w, out, steps, wsteps, 4);
     run_big(w, out, steps, 0);
     run_big(w, out, steps, 1);
   }

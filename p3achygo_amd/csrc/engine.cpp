@@ -607,7 +607,10 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
         a.pre = lp.pre; a.act = lp.act; a.res = lp.res; a.dual = lp.dual;
         if (a.pre) { a.scale_in = e->dev<float>(lp.pre_bn.scale_off); a.shift_in = e->dev<float>(lp.pre_bn.shift_off); }
         if (a.act || a.dual) { a.scale_out = e->dev<float>(lp.out_bn.scale_off); a.shift_out = e->dev<float>(lp.out_bn.shift_off); }
+        const bool timed = e->time_blocks && lp.kw == 3 && 2 * e->timed_blocks + 1 < (int)e->blk_ev.size();
+        if (timed) hipEventRecord(e->blk_ev[2 * e->timed_blocks], s);
         if (!e->check(p3::launch_lconv(lp.kw, lp.cin, lp.cout, a, e->n_cu, s), "launch k_lconv")) return false;
+        if (timed) hipEventRecord(e->blk_ev[2 * e->timed_blocks++ + 1], s);
       }
     } else {
       const int run = fused_run(e, bi);
@@ -844,10 +847,42 @@ double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
                                double* flops_per_launch, const char** kernel_name) {
   const WeightFile& wf = e->wf;
   const BlockPlan* bp = nullptr;
-  int nfused = 0;
-  for (const BlockPlan& b : e->blocks)
-    if (b.kind == 0 || b.kind == 1) { if (!bp) bp = &b; ++nfused; }   // fused block kernel only
-  if (!bp || n_positions < 1 || n_positions > e->batch || iters < 1 || !e->bind()) return -1.0;
+  int nfused = 0, n3x3 = 0, c3 = 0;
+  for (const BlockPlan& b : e->blocks) {
+    if (b.kind == 0 || b.kind == 1) { if (!bp) bp = &b; ++nfused; }   // fused block kernel
+    if (b.kind == 4)
+      for (const LayerPlan& lp : b.layers)
+        if (lp.kw == 3) { ++n3x3; c3 = lp.cin; }
+  }
+  if (n_positions < 1 || n_positions > e->batch || iters < 1 || !e->bind()) return -1.0;
+  if (!bp && n3x3 > 0) {
+    // layer-wise trunks (C = 384, classic): the dominant kernel is the 3x3 layer conv, k_lconv<3, ..>
+    while ((int)e->blk_ev.size() < 2 * n3x3) {
+      hipEvent_t ev;
+      if (!e->check(hipEventCreate(&ev), "hipEventCreate")) return -1.0;
+      e->blk_ev.push_back(ev);
+    }
+    if (!enqueue_forward(e, n_positions)) return -1.0;   // warm-up
+    double total_ms = 0.0;
+    long launches = 0;
+    for (int i = 0; i < iters; ++i) {
+      e->time_blocks = true;
+      e->timed_blocks = 0;
+      const bool ok = enqueue_forward(e, n_positions);
+      e->time_blocks = false;
+      if (!ok || !e->check(hipStreamSynchronize(e->stream), "sync")) return -1.0;
+      for (int b = 0; b < e->timed_blocks; ++b) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, e->blk_ev[2 * b], e->blk_ev[2 * b + 1]);
+        total_ms += ms;
+        ++launches;
+      }
+    }
+    if (flops_per_launch) *flops_per_launch = 2.0 * n_positions * kNLoc * 9.0 * c3 * c3;
+    if (kernel_name) *kernel_name = c3 == 192 ? "k_lconv<3,192,192>" : "k_lconv<3,64,64>";
+    return launches ? total_ms / launches : -1.0;
+  }
+  if (!bp) return -1.0;
   // Time the kernel where it runs: whole forward passes over the resident batch, with a HIP
   // event pair (on the engine's stream) around each fused-block launch.  The average over all
   // launches is what rocprofv3 --kernel-trace --stats reports for the same run.

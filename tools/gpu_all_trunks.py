@@ -20,5 +20,11 @@ for name in names:
     for _ in range(n): eng.forward_resident(batch)
     eng.sync()
     ms = (time.perf_counter() - t0) / n * 1e3
-    print(f"{name:18s} forward {ms:7.3f} ms  {batch / ms:8.1f} k positions/s", flush=True)
+    total, conv3 = eng.flops_per_position()
+    try:
+        kms, fl, kname = eng.time_trunk_kernel(batch, 5)
+        kern = f"{kname} {kms * 1e3:7.1f} us/launch = {fl / kms / 1e9 / 2500:.3f} of 2.5 PFLOP/s"
+    except Exception as ex:  # noqa: BLE001
+        kern = "-"
+    print(f"{name:18s} forward {ms:7.3f} ms  {batch / ms:8.1f} k positions/s  whole net {total * batch / ms / 1e9:6.0f} TFLOP/s  {kern}", flush=True)
     eng.close()

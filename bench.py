@@ -35,7 +35,8 @@ import numpy as np  # noqa: E402
 
 MODEL = "b12c256btl3"
 BATCH = 1024
-DEFAULT_GROUPS = GROUPS = 4          # game groups per GPU: 3 forward passes queued while the 4th group is on the host
+DEFAULT_GROUPS = GROUPS = 6          # game groups per GPU: forward passes of the others queued while one group is on the host
+                                     # (4 / 6 / 8 / 12 groups measured 217 / 222 / 220 / 220 k positions/s on one box)
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 PF
 LADDER_BUDGET = 0       # ladder read-out work bound of the host: 0 = the reference's exact read-out (default)
 

@@ -205,6 +205,24 @@ def main():
         if prof:
             roof["algorithmic_bytes_per_launch"] = prof["algorithmic_bytes_per_launch"]
             roof["traffic_source"] = "recorded: " + prof["source"]
+        roof["launch_contents"] = ("residual blocks + the 1x1 convs of the neighbouring broadcast blocks (HBM-bound, "
+                                   "4.9 % of the FLOPs); blocks_only = the same launches with those convs as their own "
+                                   "launches (P3HIP_NO_BFUSE=1: slower forward pass, comparable with earlier rounds)")
+        if kname.startswith("k_block"):
+            os.environ["P3HIP_NO_BFUSE"] = "1"       # read by p3hip_create: this instance only
+            try:
+                eng2 = engine.create_engine(engine.kind_from_engine_path(path), path, args.batch, 1, device=local_rank)
+                eng2.load_all(pos)
+                eng2.upload()
+                for _ in range(5):
+                    eng2.forward_resident(args.batch)
+                eng2.sync()
+                ms2, fl2, _ = eng2.time_trunk_kernel(args.batch, 10)
+                roof["blocks_only"] = {"achieved": fl2 / (ms2 * 1e-3) / 1e12, "frac": fl2 / (ms2 * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
+                                       "launch_ms": ms2, "algorithmic_flops_per_launch": fl2}
+                eng2.close()
+            finally:
+                del os.environ["P3HIP_NO_BFUSE"]
     eng.close()
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         try:

@@ -46,33 +46,96 @@ inline bool WriteMatchResult(const std::string& path, float rel_elo) {
   return true;
 }
 
-struct EvalPlayerConfig {   // PlayerSearchConfig (player_config.h:20-108)
+struct EvalPlayerConfig {   // PlayerSearchConfig (player_config.h:20-108), same fields and defaults
+  // Gumbel (the legacy path with use_puct = false)
   int n = 128;                   // visit budget per move
-  // > 1: parallel mcts::Search with this many leaves per round; 1: the legacy path,
-  // GumbelEvaluator::SearchRootPuct with LCB move choice (eval.cc:99-101,262-281, use_puct /
-  // use_lcb defaults of player_config.h:29,44)
-  int num_threads_per_game = 8;
-  float c_puct = 1.0f, c_puct_visit_scaling = 0.45f, root_fpu = 0.2f;
+  int k = 8;
+  float noise_scaling = 1.0f;
+  bool early_stopping_for_gumbel = false;
+  // PUCT (GumbelEvaluator::SearchRootPuct and the parallel mcts::Search)
+  bool use_puct = true;
+  float c_puct = 1.0f, c_puct_visit_scaling = 0.45f;
   bool var_scale_cpuct = false;
-  int var_scale_prior_visits = 0;
-  // parallel-search knobs, defaults of player_config.h:76-108
-  SearchMode search_mode = SearchMode::kConcurrent;
-  QFn q_fn = QFn::kVirtualLossSoft;
-  NFn n_fn = NFn::kVirtualVisit;
-  float vl_delta = -1.5f;
-  CollisionPolicy collision_policy = CollisionPolicy::kAbort;
-  CollisionDetector collision_detector = CollisionDetector::kNoOp;
-  int max_collision_retries = 4;
-  DescentPolicy descent_policy = DescentPolicy::kDeterministic;   // "deterministic" | "bu_uct"
-  float max_o_ratio = 1.0f;
+  bool use_puct_v = false;
+  float c_puct_v_2 = 3.0f;
+  float tau = 1.0f;
+  std::string puct_root_policy;   // "visit_count" | "lcb" | "visit_count_sample"; empty: from use_lcb
+  bool use_lcb = true;
+  // score utility
+  float score_weight = kDefaultScoreWeight;
+  std::string score_utility_mode = "direct";   // | "integral"
+  // other
   bool use_mcgs = false;                                          // McgsNodeTable for this player's tree
   bool use_bias_cache = false;
   float bias_cache_alpha = 0.8f, bias_cache_lambda = 0.4f;
-  int time_ms = 0;                                                // threaded driver only: time control
+  bool enable_m3_bonus = false;
+  int var_scale_prior_visits = 0;
+  int m3_prior_visits = 20;
+  float p_opt_weight = 0.0f;
+  float root_fpu = 0.2f;
+  // parallel-search knobs (player_config.h:63-108).  num_threads_per_game > 1 (or time_ms > 0): parallel
+  // mcts::Search with this many workers / leaves per round; otherwise the legacy path, Gumbel or
+  // SearchRootPuct (eval.cc:99-101,229-269).  The match drivers of this repository set it from their
+  // own argument (reference default: 1).
+  int num_threads_per_game = 8;
+  int time_ms = 0;                                                // threaded driver only: time control ("auto" = -1)
+  bool enable_pondering = false;                                  // parsed; GTP only in the reference
+  uint32_t time_control_flags = 0;                                // parsed; cc/gtp/time_control only
+  QFn q_fn = QFn::kVirtualLossSoft;
+  NFn n_fn = NFn::kVirtualVisit;
+  CollisionPolicy collision_policy = CollisionPolicy::kAbort;
+  CollisionDetector collision_detector = CollisionDetector::kNoOp;
+  float vl_delta = -1.5f;
+  int max_collision_retries = 4;
+  SearchMode search_mode = SearchMode::kConcurrent;
+  DescentPolicy descent_policy = DescentPolicy::kDeterministic;   // "deterministic" | "bu_uct"
+  float max_o_ratio = 1.0f;
 };
 
-// ParsePlayerConfigFile (cc/eval/player_config.h:133-260): "key: value" lines, '#' comments.
-// Unknown keys are reported through *err (the reference LOG(FATAL)s on them).
+inline bool UsesParallelSearch(const EvalPlayerConfig& c) { return c.num_threads_per_game > 1 || c.time_ms > 0; }   // eval.cc:99-101
+
+// MakeScoreUtilityParams (player_config.cc:4-12)
+inline ScoreUtilityParams MakeScoreUtility(const EvalPlayerConfig& c) {
+  return ScoreUtilityParams{c.score_weight, c.score_utility_mode == "integral" ? ScoreUtilityMode::kIntegral : ScoreUtilityMode::kDirect};
+}
+// The PuctParams of the parallel search (MakeSearchParams, player_config.cc:40-54,100-113) ...
+inline PuctParams MakeSearchPuctParams(const EvalPlayerConfig& c) {
+  PuctParams p;
+  if (c.puct_root_policy == "visit_count") p.kind = PuctRootSelection::kVisitCount;
+  else if (c.puct_root_policy == "visit_count_sample") p.kind = PuctRootSelection::kVisitCountSample;
+  else if (c.puct_root_policy == "lcb" || c.puct_root_policy.empty())
+    p.kind = (c.puct_root_policy == "lcb" || c.use_lcb) ? PuctRootSelection::kLcb : PuctRootSelection::kVisitCount;
+  else p.kind = PuctRootSelection::kLcb;
+  p.c_puct = c.c_puct; p.c_puct_visit_scaling = c.c_puct_visit_scaling;
+  p.c_puct_v_2 = c.c_puct_v_2; p.use_puct_v = c.use_puct_v;
+  p.enable_var_scaling = c.var_scale_cpuct; p.var_scale_prior_visits = c.var_scale_prior_visits;
+  p.tau = c.tau;
+  p.enable_m3_bonus = c.enable_m3_bonus; p.m3_prior_visits = c.m3_prior_visits;
+  p.p_opt_weight = c.p_opt_weight; p.root_fpu = c.root_fpu;
+  return p;
+}
+// ... and of the legacy SearchRootPuct call (eval.cc:241-258: no visit scaling or tau override there)
+inline PuctParams MakeRootPuctParams(const EvalPlayerConfig& c) {
+  PuctParams p;
+  p.kind = c.use_lcb ? PuctRootSelection::kLcb : PuctRootSelection::kVisitCount;
+  p.c_puct = c.c_puct;
+  p.c_puct_v_2 = c.c_puct_v_2; p.use_puct_v = c.use_puct_v;
+  p.enable_var_scaling = c.var_scale_cpuct; p.var_scale_prior_visits = c.var_scale_prior_visits;
+  p.enable_m3_bonus = c.enable_m3_bonus; p.m3_prior_visits = c.m3_prior_visits;
+  p.p_opt_weight = c.p_opt_weight; p.root_fpu = c.root_fpu;
+  return p;
+}
+inline GumbelParams MakeGumbelParams(const EvalPlayerConfig& c) {   // eval.cc:259-267
+  GumbelParams g;
+  g.n = c.n; g.k = c.k; g.noise_scaling = c.noise_scaling;
+  g.early_stopping_enabled = c.early_stopping_for_gumbel;
+  return g;
+}
+
+// ParsePlayerConfigFile (cc/eval/player_config.h:133-244): "key: value" lines, '#' comments and blank
+// lines skipped, every PlayerSearchConfig field by its name, unknown keys ignored, enum-valued fields fall
+// back as MakeSearchParams does (player_config.cc:56-95: an unknown q_fn is virtual_loss, the others their
+// defaults).  Returns false only when the file cannot be opened or a number does not parse.
 inline bool ParsePlayerConfig(const std::string& path, EvalPlayerConfig* cfg, std::string* err) {
   std::ifstream in(path);
   if (!in) { if (err) *err = "cannot open " + path; return false; }
@@ -82,60 +145,61 @@ inline bool ParsePlayerConfig(const std::string& path, EvalPlayerConfig* cfg, st
     return x.substr(b, x.find_last_not_of(" \t\r\n") - b + 1);
   };
   std::string line;
-  while (std::getline(in, line)) {
-    line = trim(line);
-    if (line.empty() || line[0] == '#') continue;
-    const size_t colon = line.find(':');
-    if (colon == std::string::npos) { if (err) *err = "no ':' in line: " + line; return false; }
-    const std::string key = trim(line.substr(0, colon)), val = trim(line.substr(colon + 1));
-    auto b = [&] { return val == "true" || val == "1"; };
-    if (key == "n") cfg->n = std::stoi(val);
-    else if (key == "num_threads_per_game") cfg->num_threads_per_game = std::stoi(val);
-    else if (key == "c_puct") cfg->c_puct = std::stof(val);
-    else if (key == "c_puct_visit_scaling") cfg->c_puct_visit_scaling = std::stof(val);
-    else if (key == "root_fpu") cfg->root_fpu = std::stof(val);
-    else if (key == "var_scale_cpuct") cfg->var_scale_cpuct = b();
-    else if (key == "var_scale_prior_visits") cfg->var_scale_prior_visits = std::stoi(val);
-    else if (key == "use_mcgs") cfg->use_mcgs = b();
-    else if (key == "use_bias_cache") cfg->use_bias_cache = b();
-    else if (key == "bias_cache_alpha") cfg->bias_cache_alpha = std::stof(val);
-    else if (key == "bias_cache_lambda") cfg->bias_cache_lambda = std::stof(val);
-    else if (key == "time_ms") cfg->time_ms = std::stoi(val);
-    else if (key == "vl_delta") cfg->vl_delta = std::stof(val);
-    else if (key == "max_collision_retries") cfg->max_collision_retries = std::stoi(val);
-    else if (key == "max_o_ratio") cfg->max_o_ratio = std::stof(val);
-    else if (key == "q_fn") {
-      if (val == "identity") cfg->q_fn = QFn::kIdentity;
-      else if (val == "virtual_loss") cfg->q_fn = QFn::kVirtualLoss;
-      else if (val == "virtual_loss_soft") cfg->q_fn = QFn::kVirtualLossSoft;
-      else { if (err) *err = "bad q_fn: " + val; return false; }
-    } else if (key == "n_fn") {
-      if (val == "identity") cfg->n_fn = NFn::kIdentity;
-      else if (val == "virtual_visit") cfg->n_fn = NFn::kVirtualVisit;
-      else { if (err) *err = "bad n_fn: " + val; return false; }
-    } else if (key == "collision_policy") {
-      if (val == "abort") cfg->collision_policy = CollisionPolicy::kAbort;
-      else if (val == "retry") cfg->collision_policy = CollisionPolicy::kRetry;
-      else if (val == "smart_retry") cfg->collision_policy = CollisionPolicy::kSmartRetry;
-      else { if (err) *err = "bad collision_policy: " + val; return false; }
-    } else if (key == "collision_detector") {
-      if (val == "noop") cfg->collision_detector = CollisionDetector::kNoOp;
-      else if (val == "n_in_flight") cfg->collision_detector = CollisionDetector::kNInFlight;
-      else if (val == "level_saturation") cfg->collision_detector = CollisionDetector::kLevelSaturation;
-      else if (val == "product") cfg->collision_detector = CollisionDetector::kProduct;
-      else { if (err) *err = "bad collision_detector: " + val; return false; }
-    } else if (key == "search_mode") {
-      if (val == "concurrent") cfg->search_mode = SearchMode::kConcurrent;
-      else if (val == "batch") cfg->search_mode = SearchMode::kBatch;
-      else { if (err) *err = "bad search_mode: " + val; return false; }
-    } else if (key == "descent_policy") {
-      if (val == "deterministic") cfg->descent_policy = DescentPolicy::kDeterministic;
-      else if (val == "bu_uct") cfg->descent_policy = DescentPolicy::kBuUct;
-      else { if (err) *err = "bad descent_policy: " + val; return false; }
-    } else {
-      if (err) *err = "unknown key: " + key;
-      return false;
+  try {
+    while (std::getline(in, line)) {
+      line = trim(line);
+      if (line.empty() || line[0] == '#') continue;
+      const size_t colon = line.find(':');
+      if (colon == std::string::npos) continue;
+      const std::string key = trim(line.substr(0, colon)), val = trim(line.substr(colon + 1));
+      auto b = [&] { return val == "true" || val == "1"; };
+      if (key == "n") cfg->n = std::stoi(val);
+      else if (key == "k") cfg->k = std::stoi(val);
+      else if (key == "noise_scaling") cfg->noise_scaling = std::stof(val);
+      else if (key == "early_stopping_for_gumbel") cfg->early_stopping_for_gumbel = b();
+      else if (key == "use_puct") cfg->use_puct = b();
+      else if (key == "c_puct") cfg->c_puct = std::stof(val);
+      else if (key == "c_puct_visit_scaling") cfg->c_puct_visit_scaling = std::stof(val);
+      else if (key == "var_scale_cpuct") cfg->var_scale_cpuct = b();
+      else if (key == "use_puct_v") cfg->use_puct_v = b();
+      else if (key == "c_puct_v_2") cfg->c_puct_v_2 = std::stof(val);
+      else if (key == "tau") cfg->tau = std::stof(val);
+      else if (key == "puct_root_policy") cfg->puct_root_policy = val;
+      else if (key == "use_lcb") cfg->use_lcb = b();
+      else if (key == "score_weight") cfg->score_weight = std::stof(val);
+      else if (key == "score_utility_mode") cfg->score_utility_mode = val;
+      else if (key == "use_mcgs") cfg->use_mcgs = b();
+      else if (key == "use_bias_cache") cfg->use_bias_cache = b();
+      else if (key == "bias_cache_alpha") cfg->bias_cache_alpha = std::stof(val);
+      else if (key == "bias_cache_lambda") cfg->bias_cache_lambda = std::stof(val);
+      else if (key == "enable_m3_bonus") cfg->enable_m3_bonus = b();
+      else if (key == "var_scale_prior_visits") cfg->var_scale_prior_visits = std::stoi(val);
+      else if (key == "m3_prior_visits") cfg->m3_prior_visits = std::stoi(val);
+      else if (key == "p_opt_weight") cfg->p_opt_weight = std::stof(val);
+      else if (key == "root_fpu") cfg->root_fpu = std::stof(val);
+      else if (key == "num_threads_per_game") cfg->num_threads_per_game = std::stoi(val);
+      else if (key == "time_ms") cfg->time_ms = val == "auto" ? -1 : std::stoi(val);
+      else if (key == "enable_pondering") cfg->enable_pondering = b();
+      else if (key == "time_control_flags") cfg->time_control_flags = val == "all" ? ~0u : (uint32_t)std::stoul(val);
+      else if (key == "q_fn")
+        cfg->q_fn = val == "identity" ? QFn::kIdentity : val == "virtual_loss_soft" ? QFn::kVirtualLossSoft : QFn::kVirtualLoss;
+      else if (key == "n_fn") cfg->n_fn = val == "identity" ? NFn::kIdentity : NFn::kVirtualVisit;
+      else if (key == "collision_policy")
+        cfg->collision_policy = val == "retry" ? CollisionPolicy::kRetry : val == "smart_retry" ? CollisionPolicy::kSmartRetry : CollisionPolicy::kAbort;
+      else if (key == "collision_detector")
+        cfg->collision_detector = val == "n_in_flight" ? CollisionDetector::kNInFlight
+                                  : val == "level_saturation" ? CollisionDetector::kLevelSaturation
+                                  : val == "product" ? CollisionDetector::kProduct : CollisionDetector::kNoOp;
+      else if (key == "vl_delta") cfg->vl_delta = std::stof(val);
+      else if (key == "max_collision_retries") cfg->max_collision_retries = std::stoi(val);
+      else if (key == "search_mode") cfg->search_mode = val == "batch" ? SearchMode::kBatch : SearchMode::kConcurrent;
+      else if (key == "descent_policy") cfg->descent_policy = val == "bu_uct" ? DescentPolicy::kBuUct : DescentPolicy::kDeterministic;
+      else if (key == "max_o_ratio") cfg->max_o_ratio = std::stof(val);
+      // unknown keys are ignored (player_config.h:243)
     }
+  } catch (const std::exception& e) {   // the reference lets std::stoi / std::stof throw out of main
+    if (err) *err = "bad value in line: " + line;
+    return false;
   }
   return true;
 }
@@ -205,29 +269,30 @@ class EvalGame {
  private:
   void BeginSearch() {
     const int side = color_ == kBlack ? 0 : 1;
-    ParallelSearchParams p;
-    p.batch = cfg_[side].num_threads_per_game;
-    p.visit_budget = cfg_[side].n;
-    p.puct.c_puct = cfg_[side].c_puct;
-    p.puct.c_puct_visit_scaling = cfg_[side].c_puct_visit_scaling;
-    p.puct.root_fpu = cfg_[side].root_fpu;
-    p.puct.enable_var_scaling = cfg_[side].var_scale_cpuct;
-    p.puct.var_scale_prior_visits = cfg_[side].var_scale_prior_visits;
-    p.mode = cfg_[side].search_mode;
-    p.fns = VirtualFns{cfg_[side].q_fn, cfg_[side].n_fn, cfg_[side].vl_delta};
-    p.collision = cfg_[side].collision_policy;
-    p.detector = cfg_[side].collision_detector;
-    p.max_collision_retries = cfg_[side].max_collision_retries;
-    p.descent = cfg_[side].descent_policy;
-    p.max_o_ratio = cfg_[side].max_o_ratio;
-    p.bias_cache = bias_[side].get();
+    const EvalPlayerConfig& c = cfg_[side];
     puct_.set_bias_cache(bias_[side].get());
-    parallel_ = cfg_[side].num_threads_per_game > 1;   // UsesParallelSearch, eval.cc:99-101
+    puct_.set_score_utility(MakeScoreUtility(c));
+    // this scheduler has no clock: time_ms belongs to the thread-per-game driver
+    parallel_ = c.num_threads_per_game > 1;   // UsesParallelSearch, eval.cc:99-101
     if (parallel_) {
+      ParallelSearchParams p;
+      p.batch = c.num_threads_per_game;
+      p.visit_budget = c.n;
+      p.puct = MakeSearchPuctParams(c);
+      p.score_util = MakeScoreUtility(c);
+      p.mode = c.search_mode;
+      p.fns = VirtualFns{c.q_fn, c.n_fn, c.vl_delta};
+      p.collision = c.collision_policy;
+      p.detector = c.collision_detector;
+      p.max_collision_retries = c.max_collision_retries;
+      p.descent = c.descent_policy;
+      p.max_o_ratio = c.max_o_ratio;
+      p.bias_cache = bias_[side].get();
       search_.Begin(&game_, &pool_[side], tree_[side], color_, p);
-    } else {
-      p.puct.kind = PuctRootSelection::kLcb;
-      puct_.BeginPuct(&game_, &pool_[side], tree_[side], color_, cfg_[side].n, p.puct, /*tau=*/1.0f, &prob_);
+    } else if (c.use_puct) {   // GumbelEvaluator::SearchRootPuct, eval.cc:241-258
+      puct_.BeginPuct(&game_, &pool_[side], tree_[side], color_, c.n, MakeRootPuctParams(c), /*tau=*/1.0f, &prob_);
+    } else {                   // GumbelEvaluator::SearchRoot, eval.cc:259-267
+      puct_.Begin(&game_, &pool_[side], tree_[side], color_, MakeGumbelParams(c), &prob_);
     }
   }
   void FinishMove() {

@@ -27,58 +27,7 @@
 namespace p3 {
 
 
-// ---- PUCT scores, top-4 (search_policy.h:159-351) with the virtual-loss Q / N functions ----------
-enum class QFn : uint8_t { kIdentity = 0, kVirtualLoss = 1, kVirtualLossSoft = 2 };   // search_policy.h:400-446
-enum class NFn : uint8_t { kIdentity = 0, kVirtualVisit = 1 };                          // :406-459
-struct VirtualFns {
-  QFn q = QFn::kIdentity;
-  NFn n = NFn::kIdentity;
-  float vl_delta = -1.5f;
-  float Q(float q_, int n_, int in_flight) const {
-    if (q == QFn::kVirtualLoss) return q_ + in_flight * vl_delta;
-    if (q == QFn::kVirtualLossSoft) return in_flight == 0 ? q_ : (q_ * n_ + in_flight * vl_delta) / (float)(n_ + in_flight);
-    return q_;
-  }
-  float N(int n_, int in_flight) const { return n == NFn::kVirtualVisit ? (float)(n_ + in_flight) : (float)n_; }
-};
-
-inline void PuctScoresAll(const TreeNode* node, const PuctParams& pp, bool is_root, float* scores,
-                          const VirtualFns& vf = VirtualFns{}) {
-  const int n = node->n;
-  const float v = node->v;
-  int cv[kNumMoves] = {}, inflight[kNumMoves] = {};
-  float qs[kNumMoves], qvars[kNumMoves];
-  float q_std_weighted = 0;
-  for (const ChildEdge& e : node->children) {
-    cv[e.action] = e.visits;
-    if (e.node) inflight[e.action] = e.node->n_in_flight;
-    if (e.visits > 0) qs[e.action] = -e.node->v;
-    if (e.visits >= 3) {
-      qvars[e.action] = e.node->v_var;
-      q_std_weighted += std::sqrt(qvars[e.action]) * e.visits;
-    }
-  }
-  const float q_std_mean = q_std_weighted / n;
-  float p_explored = 0;
-  for (const ChildEdge& e : node->children)
-    if (e.visits + inflight[e.action] > 0) p_explored += node->move_probs[e.action];
-  const float v_fpu = v - (is_root ? pp.root_fpu : kDefaultFPU) * std::sqrt(p_explored);
-  const float c_puct = pp.c_puct + pp.c_puct_visit_scaling * std::log((n + 500.0f) / 500.0f);
-  float total_n = 1;
-  for (const ChildEdge& e : node->children) total_n += vf.N(e.visits, inflight[e.action]);
-  const float sqrt_n = std::sqrt(total_n);
-  for (int a = 0; a < kNumMoves; ++a) {
-    float scale = 1.0f;
-    if (pp.enable_var_scaling && cv[a] >= 3 && q_std_mean != 0) {
-      const float pw = (float)pp.var_scale_prior_visits;
-      scale = (pw + cv[a] * (std::sqrt(qvars[a]) / q_std_mean)) / (pw + cv[a]);
-    }
-    const float child_n = vf.N(cv[a], inflight[a]);
-    const float q = vf.Q(cv[a] > 0 ? qs[a] : v_fpu, cv[a], inflight[a]);
-    scores[a] = c_puct * scale * node->move_probs[a] * (sqrt_n / (1 + child_n)) + q;
-  }
-}
-
+// ---- top-4 PUCT scores (PuctScorer::TopScores, search_policy.h:318-351; the scorer is in search.h) ----
 using TopActions = std::array<std::pair<int, float>, 4>;   // (action or -1, score)
 inline TopActions PuctTopScores(const TreeNode* node, const Board& board, Color color, const PuctParams& pp,
                                 bool is_root, const VirtualFns& vf = VirtualFns{}) {   // search_policy.h:318-351
@@ -147,6 +96,7 @@ struct ParallelSearchParams {   // Search::Params (search.h:92-107)
   // the reference runs the workers on threads, here they descend one after the other.
   SearchMode mode = SearchMode::kBatch;
   VirtualFns fns;               // q_fn_kind / n_fn_kind / vl_delta
+  ScoreUtilityParams score_util;   // score_util_params (search.h Params; player_config.cc:128)
   CollisionPolicy collision = CollisionPolicy::kAbort;
   int max_collision_retries = 4;
   CollisionDetector detector = CollisionDetector::kNoOp;
@@ -434,10 +384,10 @@ class BatchSearch {
       Worker& w = workers_[wi];
       if (w.aborted) continue;
       TreeNode* leaf = w.path.back().node;
-      if (w.needs_eval) EvaluateLeaf(pending_[w.eval_slot], leaf, w.leaf_color, color_, root_->init_score_est);
+      if (w.needs_eval) EvaluateLeaf(pending_[w.eval_slot], leaf, w.leaf_color, color_, root_->init_score_est, p_.score_util);
       if (w.pos.IsGameOver()) {
         Scores s = w.pos.GetScores();
-        EvaluateTerminal(s, leaf, w.leaf_color, color_, root_->init_score_est);
+        EvaluateTerminal(s, leaf, w.leaf_color, color_, root_->init_score_est, p_.score_util);
         leaf->evaluated = true;
       }
       AssignBiasCacheEntry(p_.bias_cache, w.pos, leaf);   // search.cc:251

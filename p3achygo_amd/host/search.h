@@ -216,6 +216,60 @@ inline float ScoreTransform(float c_score, float score_est, float root_score_est
   return c_score * (float)M_2_PI * std::atan((score_est - root_score_est) / kBoardLen);
 }
 
+// ScoreUtilityParams / ScoreUtilityMode (leaf_evaluator.h:12-17): `direct` is the transform above,
+// `integral` its expectation under a normal score distribution, read from a table over (score mean,
+// score stddev) with bilinear interpolation (leaf_evaluator.cc:12-76; the same float / double
+// arithmetic, including the z loop's accumulated float steps).
+enum class ScoreUtilityMode : uint8_t { kDirect = 0, kIntegral = 1 };
+struct ScoreUtilityParams {
+  float score_weight = kDefaultScoreWeight;
+  ScoreUtilityMode mode = ScoreUtilityMode::kDirect;
+};
+constexpr int kNumScoreMeans = P3HIP_NUM_SCORE_LOGITS, kNumScoreStddevs = P3HIP_NUM_SCORE_LOGITS / 2;
+constexpr int kScoreInflectionPoint = 400;   // constants::kScoreInflectionPoint
+inline const std::vector<float>& ScoreTransformTable() {   // kScoreTransformTable, :20-46
+  static const std::vector<float> table = [] {
+    constexpr float kZStep = 0.1f, kZBound = 5.0f;
+    std::vector<float> t((size_t)kNumScoreMeans * kNumScoreStddevs);
+    for (int score_idx = 0; score_idx < kNumScoreMeans; ++score_idx) {
+      const float score_mean = score_idx - kScoreInflectionPoint + 0.5f;
+      for (int stddev = 0; stddev < kNumScoreStddevs; ++stddev) {
+        float total_pdf_mass = 0.0f, integral_unnormalized = 0.0f;
+        for (float z = -kZBound; z <= kZBound; z += kZStep) {
+          const float pdf_scaled = std::exp(-0.5 * z * z);
+          const float score_transform = M_2_PI * std::atan((score_mean + z * stddev) / kBoardLen);
+          total_pdf_mass += pdf_scaled;
+          integral_unnormalized += score_transform * pdf_scaled;
+        }
+        t[(size_t)score_idx * kNumScoreStddevs + stddev] = integral_unnormalized / total_pdf_mass;
+      }
+    }
+    return t;
+  }();
+  return table;
+}
+inline float ScoreTransformIntegral(float c_score, float score_est, float score_stddev, float root_score_est) {   // :48-76
+  const float root_score_normalized = 0.75f * root_score_est;
+  const float score_mean = score_est - root_score_normalized;
+  const int score_floored = std::floor(score_mean - 0.5f);
+  const int stddev_floored = std::floor(score_stddev);
+  const int score_idx = std::clamp(score_floored + kScoreInflectionPoint, 0, kNumScoreMeans - 2);
+  const int stddev_idx = std::clamp(stddev_floored, 0, kNumScoreStddevs - 2);
+  const float mean_delta = (score_mean - 0.5f) - float(score_floored);
+  const float stddev_delta = score_stddev - float(stddev_floored);
+  const std::vector<float>& t = ScoreTransformTable();
+  auto at = [&](int x, int y) { return t[(size_t)x * kNumScoreStddevs + y]; };
+  const float a00 = at(score_idx, stddev_idx), a01 = at(score_idx, stddev_idx + 1);
+  const float a10 = at(score_idx + 1, stddev_idx), a11 = at(score_idx + 1, stddev_idx + 1);
+  const float b0 = a00 + stddev_delta * (a01 - a00);
+  const float b1 = a10 + stddev_delta * (a11 - a10);
+  return c_score * (b0 + mean_delta * (b1 - b0));
+}
+inline float ScoreUtility(const ScoreUtilityParams& sp, float score_est, float score_stddev, float root_score_est) {   // :125-132
+  if (sp.mode == ScoreUtilityMode::kIntegral) return ScoreTransformIntegral(sp.score_weight, score_est, score_stddev, root_score_est);
+  return ScoreTransform(sp.score_weight, score_est, root_score_est);
+}
+
 inline void InitFields(const p3hip_result& r, TreeNode* node, Color color_to_move) {   // :83-112
   std::memcpy(node->move_logits, r.move_logits, sizeof node->move_logits);
   std::memcpy(node->move_probs, r.move_probs, sizeof node->move_probs);
@@ -247,20 +301,21 @@ inline void EvaluateRoot(const p3hip_result& r, TreeNode* node, Color c) {   // 
 }
 
 inline void EvaluateLeaf(const p3hip_result& r, TreeNode* node, Color c, Color root_color,
-                         float root_score_est) {   // :152-162 (ScoreUtilityMode::kDirect)
+                         float root_score_est, const ScoreUtilityParams& sp = ScoreUtilityParams{}) {   // :152-162
   InitFields(r, node, c);
   root_score_est *= c == root_color ? 1.0f : -1.0f;
-  node->init_util_est = node->init_outcome_est + ScoreTransform(kDefaultScoreWeight, node->init_score_est, root_score_est);
+  node->init_util_est = node->init_outcome_est +
+                        ScoreUtility(sp, node->init_score_est, std::sqrt(node->init_score_var), root_score_est);
   node->evaluated.store(true, std::memory_order_release);
 }
 
 inline void EvaluateTerminal(const Scores& s, TreeNode* node, Color c, Color root_color,
-                             float root_score_est) {   // :164-186
+                             float root_score_est, const ScoreUtilityParams& sp = ScoreUtilityParams{}) {   // :164-186
   float ps = c == kBlack ? s.black_score : s.white_score;
   float os = c == kBlack ? s.white_score : s.black_score;
   float final_score = ps - os;
   root_score_est *= c == root_color ? 1.0f : -1.0f;
-  float su = ScoreTransform(kDefaultScoreWeight, final_score, root_score_est);
+  float su = ScoreUtility(sp, final_score, 0.0f, root_score_est);
   node->color_to_move = c;
   node->is_terminal = true;
   node->init_util_est = (ps > os ? 1.0f : -1.0f) + su;
@@ -425,52 +480,118 @@ inline float ComputeKLD(const float* target, const float* prior) {
 }
 
 enum class PuctRootSelection { kVisitCount = 0, kLcb = 1, kVisitCountSample = 2 };   // search_policy.h:18-22
-struct PuctParams {
+struct PuctParams {   // search_policy.h:24-44
   PuctRootSelection kind = PuctRootSelection::kVisitCountSample;   // self-play's fast moves
   float c_puct = 1.0f, c_puct_visit_scaling = 0.45f;
+  float c_puct_v_2 = 3.0f;
+  bool use_puct_v = false;          // PUCT-V exploration term instead of the PUCT one
   bool enable_var_scaling = false;
   int var_scale_prior_visits = 0;
+  float tau = 1.0f;
+  bool enable_m3_bonus = false;     // skewness bonus (third central moment of a child's values)
+  int m3_prior_visits = 20;
+  float p_opt_weight = 0.0f;        // prior = (1 - w) * move_probs + w * opt_probs
   float root_fpu = kDefaultFPU;
 };
 
-inline int PuctTopMove(const TreeNode* node, const Board& board, Color color, const PuctParams& pp,
-                       bool is_root = false) {
+// ---- PUCT scores (PuctScorer::ComputeScores, search_policy.h:159-316) with the virtual-loss Q / N
+// functions of the parallel search (identity in the serial searches) --------------------------------
+enum class QFn : uint8_t { kIdentity = 0, kVirtualLoss = 1, kVirtualLossSoft = 2 };   // search_policy.h:400-446
+enum class NFn : uint8_t { kIdentity = 0, kVirtualVisit = 1 };                          // :406-459
+struct VirtualFns {
+  QFn q = QFn::kIdentity;
+  NFn n = NFn::kIdentity;
+  float vl_delta = -1.5f;
+  float Q(float q_, int n_, int in_flight) const {
+    if (q == QFn::kVirtualLoss) return q_ + in_flight * vl_delta;
+    if (q == QFn::kVirtualLossSoft) return in_flight == 0 ? q_ : (q_ * n_ + in_flight * vl_delta) / (float)(n_ + in_flight);
+    return q_;
+  }
+  float N(int n_, int in_flight) const { return n == NFn::kVirtualVisit ? (float)(n_ + in_flight) : (float)n_; }
+};
+
+inline float ScaleCPuct(float c_puct, float c_puct_visit_scaling, int n) {   // :152-157
+  return c_puct + c_puct_visit_scaling * std::log((n + 500.0f) / 500.0f);
+}
+
+inline void PuctScoresAll(const TreeNode* node, const PuctParams& pp, bool is_root, float* scores,
+                          const VirtualFns& vf = VirtualFns{}) {
   const int n = node->n;
-  const float v = node->v;
-  int cv[kNumMoves] = {};
+  const float v = node->v, v_var = node->v_var;
+  // the prior: the policy, the optimistic policy, or a blend (:171-185)
+  float mp[kNumMoves];
+  for (int a = 0; a < kNumMoves; ++a) {
+    if (pp.p_opt_weight == 0.0f) mp[a] = node->move_probs[a];
+    else if (pp.p_opt_weight == 1.0f) mp[a] = node->opt_probs[a];
+    else mp[a] = node->move_probs[a] + pp.p_opt_weight * (node->opt_probs[a] - node->move_probs[a]);
+  }
+  int cv[kNumMoves] = {}, inflight[kNumMoves] = {};
   float qs[kNumMoves], qvars[kNumMoves];
+  double q_m3s[kNumMoves];
   float q_std_weighted = 0;
+  double q_m3_std_weighted = 0;
   for (const ChildEdge& e : node->children) {
     cv[e.action] = e.visits;
+    if (e.node) inflight[e.action] = e.node->n_in_flight;
     if (e.visits > 0) qs[e.action] = -e.node->v;
     if (e.visits >= 3) {
       qvars[e.action] = e.node->v_var;
+      q_m3s[e.action] = -e.node->v_m3;
       q_std_weighted += std::sqrt(qvars[e.action]) * e.visits;
+      q_m3_std_weighted += std::cbrt(q_m3s[e.action]) * e.visits;
     }
   }
   const float q_std_mean = q_std_weighted / n;
+  const double q_m3_std_mean = q_m3_std_weighted / n;
   float p_explored = 0;
-  for (const ChildEdge& e : node->children)
-    if (e.visits > 0) p_explored += node->move_probs[e.action];
+  for (int a = 0; a < kNumMoves; ++a)
+    if (cv[a] + inflight[a] > 0) p_explored += mp[a];
   const float v_fpu = v - (is_root ? pp.root_fpu : kDefaultFPU) * std::sqrt(p_explored);
-  const float c_puct = pp.c_puct + pp.c_puct_visit_scaling * std::log((n + 500.0f) / 500.0f);
-  float total_n = 1;
-  for (const ChildEdge& e : node->children) total_n += e.visits;
+  const float c_puct = ScaleCPuct(pp.c_puct, pp.c_puct_visit_scaling, n);
+  const float c_puct_v_2 = ScaleCPuct(pp.c_puct_v_2, pp.c_puct_visit_scaling, n);
+  float total_n = 1;   // the visit to the node itself (:216-224)
+  for (int a = 0; a < kNumMoves; ++a) total_n += vf.N(cv[a], inflight[a]);
   const float sqrt_n = std::sqrt(total_n);
-  float best = -1e6f;
-  int best_a = -1;
   for (int a = 0; a < kNumMoves; ++a) {
-    float scale = 1.0f;
+    float scale = 1.0f;   // c_puct_var_child_scale_factor (:240-251)
     if (pp.enable_var_scaling && cv[a] >= 3 && q_std_mean != 0) {
       const float pw = (float)pp.var_scale_prior_visits;
       scale = (pw + cv[a] * (std::sqrt(qvars[a]) / q_std_mean)) / (pw + cv[a]);
     }
-    const float explore = c_puct * scale * node->move_probs[a] * (sqrt_n / (1 + cv[a]));
-    const float score = explore + (cv[a] > 0 ? qs[a] : v_fpu);
-    if (score > best) {
+    const float child_n = vf.N(cv[a], inflight[a]);
+    const float q = vf.Q(cv[a] > 0 ? qs[a] : v_fpu, cv[a], inflight[a]);
+    double m3_bonus = 0.0;   // compute_m3_bonus (:262-276), as written there
+    if (pp.enable_m3_bonus && cv[a] >= 3) {
+      const float pw = (float)pp.m3_prior_visits;
+      const double abs_bonus = std::cbrt(q_m3s[a]) - q_m3_std_mean;
+      m3_bonus = (pw + abs_bonus) / double(pw + cv[a]);
+    }
+    float explore;
+    if (pp.use_puct_v) {   // compute_puct_v_explore_term (:279-288)
+      const float var = cv[a] < 3 ? (n < 3 ? 1.0f : v_var) : qvars[a];
+      const float stddev = std::sqrt(var);
+      const float var_scale_term = mp[a] * stddev * (sqrt_n / (1 + child_n));
+      const float n_scale_term = mp[a] * std::log(total_n) / (1 + child_n);
+      explore = c_puct * var_scale_term + c_puct_v_2 * n_scale_term;
+    } else {               // compute_puct_explore_term (:291-294)
+      explore = c_puct * scale * mp[a] * (sqrt_n / (1 + child_n));
+    }
+    scores[a] = (float)(explore + q + m3_bonus);
+  }
+}
+
+// PuctScorer::TopMove (search_policy.h:353-368): the best-scoring legal move.
+inline int PuctTopMove(const TreeNode* node, const Board& board, Color color, const PuctParams& pp,
+                       bool is_root = false) {
+  float scores[kNumMoves];
+  PuctScoresAll(node, pp, is_root, scores);
+  float best = -1e6f;
+  int best_a = -1;
+  for (int a = 0; a < kNumMoves; ++a) {
+    if (scores[a] > best) {
       Loc mv = a == kPassEncoding ? kPassLoc : AsLoc(a);
-      if (board.IsValidMove(mv, color)) {   // TopMove, search_policy.h:353-368
-        best = score;
+      if (board.IsValidMove(mv, color)) {
+        best = scores[a];
         best_a = a;
       }
     }
@@ -559,7 +680,7 @@ class GumbelSearch {
           if (StartVisit()) return Status::kNeedEval;   // else visit completed synchronously
           break;
         case State::kLeafEvalWait:
-          EvaluateLeaf(pending_, path_.back().node, leaf_color_, color_, root_->init_score_est);
+          EvaluateLeaf(pending_, path_.back().node, leaf_color_, color_, root_->init_score_est, score_util_);
           CompleteVisit();
           state_ = State::kNextVisit;
           break;
@@ -570,6 +691,7 @@ class GumbelSearch {
   }
   void Resume(const p3hip_result& r) { pending_ = r; }
   // GumbelEvaluator's bias_cache constructor argument (gumbel.cc:247-254); nullptr = off
+  void set_score_utility(const ScoreUtilityParams& sp) { score_util_ = sp; }
   void set_bias_cache(BiasCache* cache) { bias_cache_ = cache; }
   const Position* eval_game() const { return eval_game_; }
   Color eval_color() const { return eval_color_; }
@@ -805,7 +927,7 @@ class GumbelSearch {
     TreeNode* leaf = path_.back().node;
     if (search_game_.IsGameOver() && !leaf->is_terminal) {
       Scores s = search_game_.GetScores();
-      EvaluateTerminal(s, leaf, leaf_color_, color_, root_->init_score_est);
+      EvaluateTerminal(s, leaf, leaf_color_, color_, root_->init_score_est, score_util_);
       leaf->evaluated = true;
     }
     AssignBiasCacheEntry(bias_cache_, search_game_, leaf);   // gumbel.cc:683,724
@@ -958,6 +1080,7 @@ class GumbelSearch {
   Position root_pos_, search_game_;
   bool puct_root_ = false;
   PuctParams puct_pp_;
+  ScoreUtilityParams score_util_;   // GumbelEvaluator's ScoreUtilityParams (gumbel.h ctor; eval.cc:170,178)
   std::vector<std::pair<int, int>> pre_visits_;
   std::vector<PathEntry> path_;
   Color leaf_color_ = kBlack;

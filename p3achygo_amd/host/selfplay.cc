@@ -1164,11 +1164,8 @@ int p3host_eval_match_threads(const char* engine_lib, const char* cur_weights, c
         p.num_threads = c.num_threads_per_game;
         p.total_visit_budget = c.time_ms > 0 ? (1 << 30) : c.n;
         p.total_visit_time_ms = c.time_ms;
-        p.puct.c_puct = c.c_puct;
-        p.puct.c_puct_visit_scaling = c.c_puct_visit_scaling;
-        p.puct.root_fpu = c.root_fpu;
-        p.puct.enable_var_scaling = c.var_scale_cpuct;
-        p.puct.var_scale_prior_visits = c.var_scale_prior_visits;
+        p.puct = MakeSearchPuctParams(c);
+        p.score_util = MakeScoreUtility(c);
         p.fns = VirtualFns{c.q_fn, c.n_fn, c.vl_delta};
         p.descent = c.descent_policy;
         p.collision = c.collision_policy;
@@ -1218,17 +1215,60 @@ void p3host_match_summary(int num_cand_won, int num_games, float* out4) {
   const MatchSummary m = SummarizeMatch(num_cand_won, num_games);
   out4[0] = m.winrate; out4[1] = m.c95; out4[2] = m.rel_elo; out4[3] = m.elo_c95;
 }
-// parses a player config file; returns 0 and fills out[0..15] with its fields, or 1 with a message
+// parses a player config file; returns 0 and fills out[0..39] with its fields (order below), or 1 with a message
 int p3host_parse_player_config(const char* path, float* out, char* err) {
   EvalPlayerConfig c;
   std::string e;
   if (!ParsePlayerConfig(path, &c, &e)) { if (err) snprintf(err, 256, "%s", e.c_str()); return 1; }
-  const float v[16] = {(float)c.n, (float)c.num_threads_per_game, c.c_puct, c.c_puct_visit_scaling, c.root_fpu,
+  const PuctParams sp = MakeSearchPuctParams(c), rp = MakeRootPuctParams(c);
+  const ScoreUtilityParams su = MakeScoreUtility(c);
+  const float v[40] = {(float)c.n, (float)c.num_threads_per_game, c.c_puct, c.c_puct_visit_scaling, c.root_fpu,
                        (float)c.var_scale_cpuct, (float)(int)c.q_fn, (float)(int)c.n_fn, (float)(int)c.collision_policy,
                        (float)(int)c.collision_detector, (float)(int)c.search_mode, (float)(int)c.descent_policy,
-                       c.max_o_ratio, (float)c.use_mcgs, (float)c.use_bias_cache, (float)c.time_ms};
+                       c.max_o_ratio, (float)c.use_mcgs, (float)c.use_bias_cache, (float)c.time_ms,
+                       // 16..
+                       (float)c.k, c.noise_scaling, (float)c.early_stopping_for_gumbel, (float)c.use_puct,
+                       (float)c.use_puct_v, c.c_puct_v_2, c.tau, (float)c.use_lcb, c.score_weight, (float)(int)su.mode,
+                       // 26..
+                       (float)c.enable_m3_bonus, (float)c.var_scale_prior_visits, (float)c.m3_prior_visits, c.p_opt_weight,
+                       (float)c.enable_pondering, (float)c.time_control_flags, c.vl_delta, (float)c.max_collision_retries,
+                       // 34..: derived parameters
+                       (float)(int)sp.kind, (float)(int)rp.kind, rp.c_puct_visit_scaling, rp.tau, (float)UsesParallelSearch(c),
+                       c.bias_cache_alpha};
   std::memcpy(out, v, sizeof v);
   return 0;
+}
+
+// PuctScorer::ComputeScores on a hand-built node (tests): children given as (action, visits, v, v_var, v_m3,
+// n_in_flight); pp = {c_puct, c_puct_visit_scaling, c_puct_v_2, use_puct_v, enable_var_scaling,
+// var_scale_prior_visits, enable_m3_bonus, m3_prior_visits, p_opt_weight, root_fpu}; fns = {q_fn, n_fn, vl_delta}
+void p3host_test_puct_scores(int node_n, float node_v, float node_v_var, const float* move_probs, const float* opt_probs,
+                             int n_children, const int* actions, const int* visits, const float* child_v,
+                             const float* child_v_var, const double* child_v_m3, const int* in_flight,
+                             const float* ppv, const float* fns, int is_root, float* scores) {
+  NodePool pool;
+  TreeNode* node = pool.Create();
+  node->n = node_n; node->v = node_v; node->v_var = node_v_var;
+  std::memcpy(node->move_probs, move_probs, sizeof node->move_probs);
+  std::memcpy(node->opt_probs, opt_probs, sizeof node->opt_probs);
+  for (int i = 0; i < n_children; ++i) {
+    TreeNode* ch = pool.Create();
+    ch->v = child_v[i]; ch->v_var = child_v_var[i]; ch->v_m3 = child_v_m3[i];
+    ch->n_in_flight = in_flight[i];
+    node->children.push_back(ChildEdge{(int16_t)actions[i], visits[i], ch});
+  }
+  PuctParams pp;
+  pp.c_puct = ppv[0]; pp.c_puct_visit_scaling = ppv[1]; pp.c_puct_v_2 = ppv[2]; pp.use_puct_v = ppv[3] != 0;
+  pp.enable_var_scaling = ppv[4] != 0; pp.var_scale_prior_visits = (int)ppv[5]; pp.enable_m3_bonus = ppv[6] != 0;
+  pp.m3_prior_visits = (int)ppv[7]; pp.p_opt_weight = ppv[8]; pp.root_fpu = ppv[9];
+  const VirtualFns vf{(QFn)(int)fns[0], (NFn)(int)fns[1], fns[2]};
+  PuctScoresAll(node, pp, is_root != 0, scores, vf);
+}
+
+// LeafEvaluator::ScoreUtility (leaf_evaluator.cc:125-132)
+float p3host_test_score_utility(int integral, float score_weight, float score_est, float score_stddev, float root_score_est) {
+  return ScoreUtility(ScoreUtilityParams{score_weight, integral ? ScoreUtilityMode::kIntegral : ScoreUtilityMode::kDirect},
+                      score_est, score_stddev, root_score_est);
 }
 
 }  // extern "C"

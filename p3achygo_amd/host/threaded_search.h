@@ -31,6 +31,7 @@ class ThreadedSearch {
     int total_visit_budget = 128;
     int total_visit_time_ms = 0;
     PuctParams puct;
+    ScoreUtilityParams score_util;
     VirtualFns fns{QFn::kVirtualLossSoft, NFn::kVirtualVisit, -1.5f};
     DescentPolicy descent = DescentPolicy::kDeterministic;
     CollisionPolicy collision = CollisionPolicy::kAbort;
@@ -228,7 +229,7 @@ class ThreadedSearch {
     // FetchLeafEval, search.cc:54-71
     if (*needs_eval) {
       const p3hip_result r = slot_.FetchEntry(worker_id, game, c);
-      EvaluateLeaf(r, leaf, c, root_color_, root_->init_score_est);
+      EvaluateLeaf(r, leaf, c, root_color_, root_->init_score_est, p_.score_util);
       {
         std::lock_guard<std::mutex> l(g_.mu);
         g_.pending--;
@@ -237,7 +238,7 @@ class ThreadedSearch {
     }
     if (game.IsGameOver()) {
       Scores s = game.GetScores();
-      EvaluateTerminal(s, leaf, c, root_color_, root_->init_score_est);
+      EvaluateTerminal(s, leaf, c, root_color_, root_->init_score_est, p_.score_util);
       leaf->evaluated.store(true, std::memory_order_release);
     }
     AssignBiasCacheEntry(bias_cache_, Position(game), leaf);

@@ -150,22 +150,209 @@ def test_relative_elo_and_match_summary(L):
 
 
 def test_player_config_file(L, tmp_path):
-    """ParsePlayerConfigFile (player_config.h:133-260): key: value lines, comments, enums by name;
-    an unknown key is an error."""
+    """ParsePlayerConfigFile (player_config.h:133-244): key: value lines, comments, every PlayerSearchConfig
+    field by name, unknown keys ignored, enum strings falling back as MakeSearchParams does; and the
+    parameter sets derived from it (MakeSearchParams / the SearchRootPuct call of eval.cc:241-258)."""
     L.p3host_parse_player_config.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p]
     p = tmp_path / "cand.cfg"
     p.write_text("# candidate\nn: 200\nnum_threads_per_game: 16\nc_puct: 1.25\n\nq_fn: virtual_loss\nn_fn: identity\n"
                  "collision_policy: smart_retry\ncollision_detector: product\nsearch_mode: batch\n"
-                 "descent_policy: bu_uct\nmax_o_ratio: 0.7\nuse_mcgs: true\nuse_bias_cache: 1\ntime_ms: 250\n")
-    out = np.zeros(16, np.float32)
+                 "descent_policy: bu_uct\nmax_o_ratio: 0.7\nuse_mcgs: true\nuse_bias_cache: 1\ntime_ms: 250\n"
+                 "k: 4\nnoise_scaling: 0.5\nearly_stopping_for_gumbel: true\nuse_puct: false\nuse_puct_v: true\n"
+                 "c_puct_v_2: 2.5\ntau: 0.75\nuse_lcb: false\nscore_weight: 0.25\nscore_utility_mode: integral\n"
+                 "enable_m3_bonus: true\nvar_scale_prior_visits: 7\nm3_prior_visits: 11\np_opt_weight: 0.3\n"
+                 "enable_pondering: true\ntime_control_flags: all\nvl_delta: -2.0\nmax_collision_retries: 9\n"
+                 "puct_root_policy: visit_count_sample\nname: ignored\nno_such_key: 1\nline without a colon\n")
+    out = np.zeros(40, np.float32)
     err = C.create_string_buffer(256)
     assert L.p3host_parse_player_config(str(p).encode(), out.ctypes.data, err) == 0, err.value
     assert list(out[:2]) == [200, 16] and out[2] == pytest.approx(1.25)
     assert list(out[6:12]) == [1, 0, 2, 3, 1, 1] and out[12] == pytest.approx(0.7)
     assert list(out[13:16]) == [1, 1, 250]
-    p.write_text("n: 10\nno_such_key: 1\n")
+    assert list(out[16:21]) == [4, 0.5, 1, 0, 1] and out[21] == pytest.approx(2.5) and out[22] == pytest.approx(0.75)
+    assert out[23] == 0 and out[24] == pytest.approx(0.25) and out[25] == 1          # use_lcb, score weight, integral
+    assert list(out[26:29]) == [1, 7, 11] and out[29] == pytest.approx(0.3)
+    assert out[30] == 1 and out[31] == np.float32(2 ** 32 - 1) and out[32] == -2.0 and out[33] == 9
+    assert out[34] == 2                      # parallel search: puct_root_policy wins (visit_count_sample)
+    assert out[35] == 0                      # SearchRootPuct: use_lcb false -> visit count
+    assert out[36] == pytest.approx(0.45) and out[37] == 1.0   # ... and the defaults eval.cc does not override there
+    assert out[38] == 1
+    # defaults (player_config.h:20-108; this repository's drivers set num_threads_per_game themselves), enum
+    # fall-backs (player_config.cc:56-95) and the root policy derived from use_lcb when no policy is named
+    p.write_text("q_fn: bogus\nn_fn: bogus\ncollision_policy: bogus\ncollision_detector: bogus\nsearch_mode: bogus\n"
+                 "descent_policy: bogus\ntime_ms: auto\n")
+    assert L.p3host_parse_player_config(str(p).encode(), out.ctypes.data, err) == 0
+    assert list(out[6:12]) == [1, 1, 0, 0, 0, 0] and out[15] == -1
+    assert out[1] == 8 and out[38] == 1      # this repository's default worker count: the parallel search
+    assert list(out[16:21]) == [8, 1.0, 0, 1, 0] and out[23] == 1 and out[24] == 0.5 and out[25] == 0
+    assert list(out[26:30]) == [0, 0, 20, 0.0] and out[34] == 1 and out[35] == 1 and out[39] == pytest.approx(0.8)
+    p.write_text("n: ten\n")
     assert L.p3host_parse_player_config(str(p).encode(), out.ctypes.data, err) == 1
-    assert b"no_such_key" in err.value
+
+
+def _puct_scores_restated(n, v, v_var, mp, op, children, pp, fns, is_root):
+    """search_policy.h:159-316 in numpy float32 / float64 as the C++ types dictate; children = list of
+    (action, visits, v, v_var, v_m3, in_flight)."""
+    f = np.float32
+    c_puct, cvs, c_v2, use_v, var_scale, var_prior, m3_on, m3_prior, p_opt, root_fpu = pp
+    qk, nk, vl = fns
+    if p_opt == 0:
+        prob = mp.astype(f)
+    elif p_opt == 1:
+        prob = op.astype(f)
+    else:
+        prob = (mp + f(p_opt) * (op - mp)).astype(f)
+    A = len(mp)
+    cv, fl = np.zeros(A, int), np.zeros(A, int)
+    qs, qvars, qm3 = np.zeros(A, f), np.zeros(A, f), np.zeros(A, np.float64)
+    qstd_w, qm3_w = f(0), 0.0
+    for a, vis, cvv, cvar, cm3, inf in children:
+        cv[a], fl[a] = vis, inf
+        if vis > 0:
+            qs[a] = -f(cvv)
+        if vis >= 3:
+            qvars[a], qm3[a] = f(cvar), -cm3
+            qstd_w = f(qstd_w + np.sqrt(f(cvar)) * f(vis))
+            qm3_w += np.cbrt(qm3[a]) * vis
+    qstd_mean, qm3_mean = f(qstd_w / f(n)), qm3_w / n
+    p_expl = f(0)
+    for a in range(A):
+        if cv[a] + fl[a] > 0:
+            p_expl = f(p_expl + prob[a])
+    v_fpu = f(f(v) - f(root_fpu if is_root else 0.2) * np.sqrt(p_expl))
+    scale = lambda c: f(f(c) + f(cvs) * np.log(f(f(n + f(500)) / f(500))))
+    cp, cp2 = scale(c_puct), scale(c_v2)
+    N = lambda a: f(cv[a] + fl[a]) if nk == 1 else f(cv[a])
+    def Q(q, a):
+        if qk == 1:
+            return f(q + f(fl[a]) * f(vl))
+        if qk == 2:
+            return q if fl[a] == 0 else f(f(q * f(cv[a]) + f(fl[a]) * f(vl)) / f(cv[a] + fl[a]))
+        return q
+    total_n = f(1)
+    for a in range(A):
+        total_n = f(total_n + N(a))
+    out = np.zeros(A, f)
+    for a in range(A):
+        sc = f(1)
+        if var_scale and cv[a] >= 3 and qstd_mean != 0:
+            sc = f(f(f(var_prior) + f(cv[a]) * f(np.sqrt(qvars[a]) / qstd_mean)) / f(f(var_prior) + f(cv[a])))
+        cn = N(a)
+        q = Q(qs[a] if cv[a] > 0 else v_fpu, a)
+        m3b = 0.0
+        if m3_on and cv[a] >= 3:
+            m3b = (float(f(m3_prior)) + (np.cbrt(qm3[a]) - qm3_mean)) / float(f(m3_prior) + f(cv[a]))
+        if use_v:
+            var = (f(1) if n < 3 else f(v_var)) if cv[a] < 3 else qvars[a]
+            sd = np.sqrt(f(var))
+            vs = f(f(prob[a] * sd) * f(np.sqrt(total_n) / f(1 + cn)))
+            ns = f(f(prob[a] * np.log(total_n)) / f(1 + cn))
+            ex = f(f(cp * vs) + f(cp2 * ns))
+        else:
+            ex = f(f(f(cp * sc) * prob[a]) * f(np.sqrt(total_n) / f(1 + cn)))
+        out[a] = f(float(f(ex + q)) + m3b)
+    return out
+
+
+@pytest.mark.parametrize("variant", ["puct", "puct_v", "m3_var_popt", "virtual"])
+def test_puct_scorer_known_answers(L, variant):
+    """PuctScorer::ComputeScores with every term of search_policy.h:159-316 — optimistic-policy blend, FPU,
+    visit-scaled c_puct, variance scaling, PUCT-V, the third-moment bonus, virtual-loss Q / N — against an
+    independent numpy restatement on a hand-built node."""
+    rng = np.random.default_rng(5)
+    A = 362
+    mp = rng.dirichlet(np.full(A, 0.3)).astype(np.float32)
+    op = rng.dirichlet(np.full(A, 0.3)).astype(np.float32)
+    acts = [3, 40, 41, 100, 200, 361]
+    children = [(3, 12, 0.21, 0.05, 0.004, 0), (40, 3, -0.4, 0.2, -0.02, 1), (41, 1, 0.6, 0.0, 0.0, 0),
+                (100, 7, -0.1, 0.09, 0.011, 2), (200, 0, 0.0, 0.0, 0.0, 1), (361, 2, 0.05, 0.01, 0.0, 0)]
+    n, v, v_var = 26, 0.07, 0.12
+    pp = {"puct": [1.0, 0.45, 3.0, 0, 0, 0, 0, 20, 0.0, 0.2],
+          "puct_v": [1.1, 0.3, 2.5, 1, 0, 0, 0, 20, 1.0, 0.05],
+          "m3_var_popt": [0.9, 0.45, 3.0, 0, 1, 4, 1, 11, 0.35, 0.1],
+          "virtual": [1.0, 0.45, 3.0, 0, 1, 0, 0, 20, 0.0, 0.2]}[variant]
+    fns = [2, 1, -1.5] if variant == "virtual" else ([1, 0, -0.5] if variant == "puct_v" else [0, 0, -1.5])
+    L.p3host_test_puct_scores.argtypes = [C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + \
+        [C.c_int, C.c_void_p]
+    ia = lambda k: np.array([c[k] for c in children], np.int32)
+    fa = lambda k: np.array([c[k] for c in children], np.float32)
+    m3 = np.array([c[4] for c in children], np.float64)
+    ppv, fv = np.array(pp, np.float32), np.array(fns, np.float32)
+    for is_root in (0, 1):
+        got = np.zeros(A, np.float32)
+        a_, vis_, v_, var_, fl_ = ia(0), ia(1), fa(2), fa(3), ia(5)
+        L.p3host_test_puct_scores(n, v, v_var, mp.ctypes.data, op.ctypes.data, len(children), a_.ctypes.data, vis_.ctypes.data,
+                                  v_.ctypes.data, var_.ctypes.data, m3.ctypes.data, fl_.ctypes.data, ppv.ctypes.data,
+                                  fv.ctypes.data, is_root, got.ctypes.data)
+        want = _puct_scores_restated(n, v, v_var, mp, op, children, pp, fns, bool(is_root))
+        assert np.abs(got - want).max() < 2e-6, (variant, is_root, np.abs(got - want).max())
+        assert int(np.argmax(got)) == int(np.argmax(want))
+
+
+def _score_table_entry(score_idx, stddev):
+    f = np.float32
+    score_mean = f(score_idx - 400 + 0.5)
+    mass, acc, z = f(0), f(0), f(-5.0)
+    while z <= f(5.0):
+        pdf = f(np.exp(-0.5 * float(z) * float(z)))
+        st = f((2.0 / np.pi) * float(np.arctan(f(f(score_mean + f(z * f(stddev))) / f(19)))))
+        mass, acc = f(mass + pdf), f(acc + f(st * pdf))
+        z = f(z + f(0.1))
+    return f(acc / mass)
+
+
+def test_score_utility_modes(L):
+    """LeafEvaluator::ScoreUtility (leaf_evaluator.cc:12-132): the direct arctan transform and its
+    Gaussian-smoothed `integral` form (table over score mean x stddev, bilinear interpolation, 0.75 of the
+    root's score estimate as the reference point), against a numpy restatement of the same loops."""
+    L.p3host_test_score_utility.restype = C.c_float
+    L.p3host_test_score_utility.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+    f = np.float32
+    for w, s, sd, root in ((0.5, 3.2, 0.0, 1.0), (0.5, -12.75, 4.6, 2.5), (0.25, 40.1, 17.3, -6.0), (1.0, 0.49, 0.2, 0.0),
+                           (0.5, 450.0, 500.0, 0.0), (0.5, -450.0, 1.5, 0.0)):
+        direct = f(f(w) * f(2.0 / np.pi) * np.arctan(f(f(f(s) - f(root)) / f(19))))
+        assert L.p3host_test_score_utility(0, w, s, sd, root) == pytest.approx(float(direct), abs=1e-6)
+        mean = f(f(s) - f(0.75) * f(root))
+        sf, df = int(np.floor(f(mean - f(0.5)))), int(np.floor(f(sd)))
+        xi, yi = int(np.clip(sf + 400, 0, 798)), int(np.clip(df, 0, 398))
+        md, sdl = f(f(mean - f(0.5)) - f(sf)), f(f(sd) - f(df))
+        a00, a01, a10, a11 = (_score_table_entry(xi, yi), _score_table_entry(xi, yi + 1), _score_table_entry(xi + 1, yi),
+                              _score_table_entry(xi + 1, yi + 1))
+        b0, b1 = f(a00 + sdl * f(a01 - a00)), f(a10 + sdl * f(a11 - a10))
+        want = f(f(w) * f(b0 + md * f(b1 - b0)))
+        assert L.p3host_test_score_utility(1, w, s, sd, root) == pytest.approx(float(want), abs=3e-6)
+    # a flat score distribution around the reference point is worth nothing; a wide one shrinks the utility
+    assert abs(L.p3host_test_score_utility(1, 0.5, 0.0, 3.0, 0.0)) < 0.02
+    assert abs(L.p3host_test_score_utility(1, 0.5, 20.0, 30.0, 0.0)) < abs(L.p3host_test_score_utility(0, 0.5, 20.0, 30.0, 0.0))
+
+
+def test_eval_match_player_configs_cover_every_search_path(built, tmp_path):
+    """A match between two player config files (eval/main.cc --cur_config / --cand_config) through the paths
+    of eval.cc:229-269: the parallel search with PUCT-V, the third-moment bonus, the optimistic-policy blend
+    and the integral score utility on one side; on the other the legacy single-thread paths — Gumbel
+    (use_puct false) and SearchRootPuct with visit-count move choice (use_lcb false).  Reproducible, every
+    game finishes, both players search."""
+    cur, cand = tmp_path / "cur.cfg", tmp_path / "cand.cfg"
+    cur.write_text("n: 24\nnum_threads_per_game: 4\nuse_puct_v: true\nc_puct_v_2: 2.0\nenable_m3_bonus: true\n"
+                   "m3_prior_visits: 8\np_opt_weight: 0.5\nscore_utility_mode: integral\nscore_weight: 0.4\n"
+                   "var_scale_cpuct: true\nvar_scale_prior_visits: 3\nroot_fpu: 0.05\n")
+    res = []
+    for cand_text in ("n: 16\nk: 4\nnum_threads_per_game: 1\nuse_puct: false\nnoise_scaling: 0.5\n",
+                      "n: 16\nnum_threads_per_game: 1\nuse_puct: true\nuse_lcb: false\np_opt_weight: 1.0\n"
+                      "score_utility_mode: integral\n"):
+        cand.write_text(cand_text)
+        try:
+            host_api.eval_set_paths(cur_config=str(cur), cand_config=str(cand))
+            a = host_api.eval_match(None, None, num_games=4, visits_per_move=999, leaves_per_round=9, max_moves=20,
+                                    num_threads=2, seed=11)
+            b = host_api.eval_match(None, None, num_games=4, visits_per_move=999, leaves_per_round=9, max_moves=20,
+                                    num_threads=2, seed=11)
+        finally:
+            host_api.eval_set_paths()
+        assert a.games == 4 and a.moves == b.moves and a.visits == b.visits and a.positions == b.positions
+        assert a.moves == 4 * 20 and a.visits >= 4 * 10 * (16 + 24) * 0.8   # ten moves each side, the files' budgets
+        res.append((a.visits, a.positions))
+    assert res[0] != res[1]
 
 
 def test_eval_match_cache_sgf_and_result_file(built, tmp_path):

@@ -503,6 +503,17 @@ void p3host_test_init_states(uint64_t seed, int n, int* handicap_count, int* kom
 
 // MoveSelManager::Compute with the default calibration and the self-play flags
 // (kNnMctsBonus | kKldPenalty); out = modifier, bonus, penalty, q_adjust, kld_penalty, nn_mcts_bonus
+// the same with the thresholds of a calibration file (ParseCalibrationFile); counts[0..4] = entries parsed per field
+void p3host_test_move_sel_file(const char* path, int n_pre, float std_dev, float pre_kld, float nn_mcts_diff, float q,
+                               float scale, float* out, int* counts) {
+  SelMultCalibration cal = ParseCalibrationFile(path ? path : "");
+  counts[0] = (int)cal.v_outcome_stddev.size(); counts[1] = (int)cal.v_outcome_stddev_adj.size();
+  counts[2] = (int)cal.pre_kld.size(); counts[3] = (int)cal.nn_mcts_diff.size(); counts[4] = (int)cal.expected_std_by_n.size();
+  MoveSelManager m(kNnMctsBonus | kKldPenalty, cal);
+  MoveSelResult r = m.Compute(n_pre, std_dev, pre_kld, nn_mcts_diff, q, scale);
+  out[0] = r.modifier; out[1] = r.sel_bonus; out[2] = r.sel_penalty; out[3] = r.sel_q_adjust;
+  out[4] = r.sel_kld_penalty; out[5] = r.sel_nn_mcts_bonus;
+}
 void p3host_test_move_sel(int n_pre, float std_dev, float pre_kld, float nn_mcts_diff, float q, float scale, float* out) {
   SelMultCalibration cal;
   MoveSelManager m(kNnMctsBonus | kKldPenalty, cal);

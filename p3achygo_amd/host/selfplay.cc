@@ -602,6 +602,7 @@ bool g_init_state_sampling = true;
 float g_use_seen_state_prob = 0.5f, g_sel_mult_base = 0.0f, g_sel_mult_scale = 1.0f;
 float g_bias_cache_lambda = 0.0f, g_bias_cache_alpha = 0.8f;
 bool g_early_stopping = false;
+std::string g_calibration_file;
 long g_last_bias_pruned = 0;
 double g_last_bias_adj = 0;
 int g_num_groups = 2;
@@ -627,6 +628,8 @@ void p3host_selfplay_set_bias_cache(float lambda, float alpha) {
   g_bias_cache_lambda = lambda;
   g_bias_cache_alpha = alpha;
 }
+// --sel_mult_calibration_file of subsequent runs (selfplay/main.cc:64-67,224); empty = built-in thresholds
+void p3host_selfplay_set_calibration_file(const char* path) { g_calibration_file = path ? path : ""; }
 // --early_stopping_enabled of subsequent runs (selfplay/main.cc:68,260; off by default)
 void p3host_selfplay_set_early_stopping(int enabled) { g_early_stopping = enabled != 0; }
 // bias-cache entries pruned / sum of |root adjustment| over the moves of the last run or game
@@ -697,6 +700,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   cfg.bias_cache_lambda = g_bias_cache_lambda;
   cfg.bias_cache_alpha = g_bias_cache_alpha;
   cfg.early_stopping_enabled = g_early_stopping;
+  cfg.calibration = ParseCalibrationFile(g_calibration_file);
   cfg.fork_params = ForkParams::ForReuse(g_use_seen_state_prob);
   auto reuse = std::make_unique<ReuseBuffer>(seed ^ 0x676f6578706c6f69ull);
   cfg.reuse = reuse.get();

@@ -12,6 +12,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <fstream>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -140,6 +141,37 @@ struct SelMultCalibration {   // self_play_thread.h:23-36
     return it != m.end() ? it->second : def;
   }
 };
+
+// ParseCalibrationFile (selfplay/main.cc:71-118): "field.percentile=value" lines written by the RL loop from
+// the .stats files (fields v_outcome_stddev, v_outcome_stddev_adj, pre_kld, nn_mcts_diff, and
+// expected_std.n<visit bin>); '#' comments, lines without '=' or '.', and unknown fields are skipped; a
+// missing file leaves the defaults.
+inline SelMultCalibration ParseCalibrationFile(const std::string& path) {
+  SelMultCalibration calib;
+  if (path.empty()) return calib;
+  std::ifstream f(path);
+  if (!f.is_open()) return calib;
+  std::string line;
+  while (std::getline(f, line)) {
+    if (line.empty() || line[0] == '#') continue;
+    const size_t eq = line.find('=');
+    if (eq == std::string::npos) continue;
+    const std::string key = line.substr(0, eq);
+    float val;
+    try { val = std::stof(line.substr(eq + 1)); } catch (...) { continue; }
+    const size_t dot = key.find('.');
+    if (dot == std::string::npos) continue;
+    const std::string field = key.substr(0, dot), pct = key.substr(dot + 1);
+    if (field == "v_outcome_stddev") calib.v_outcome_stddev[pct] = val;
+    else if (field == "v_outcome_stddev_adj") calib.v_outcome_stddev_adj[pct] = val;
+    else if (field == "pre_kld") calib.pre_kld[pct] = val;
+    else if (field == "nn_mcts_diff") calib.nn_mcts_diff[pct] = val;
+    else if (field == "expected_std" && pct.size() > 1 && pct[0] == 'n') {
+      try { calib.expected_std_by_n[std::stoi(pct.substr(1))] = val; } catch (...) {}
+    }
+  }
+  return calib;
+}
 
 enum MoveSelFlags : uint32_t { kStddevBonus = 1, kStddevPenalty = 2, kKldBonus = 4, kKldPenalty = 8, kNnMctsBonus = 16 };
 

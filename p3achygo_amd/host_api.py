@@ -163,6 +163,14 @@ def set_bias_cache(bias_cache_lambda: float = 0.0, bias_cache_alpha: float = 0.8
     L.p3host_selfplay_set_bias_cache(bias_cache_lambda, bias_cache_alpha)
 
 
+def set_calibration_file(path: str = "") -> None:
+    """--sel_mult_calibration_file of subsequent self-play runs (selfplay/main.cc:64-67): per-generation
+    thresholds of the training-move selection multiplier; empty = the built-in ones."""
+    L = lib()
+    L.p3host_selfplay_set_calibration_file.argtypes = [C.c_char_p]
+    L.p3host_selfplay_set_calibration_file(path.encode())
+
+
 def set_early_stopping(enabled: bool) -> None:
     """--early_stopping_enabled of subsequent self-play runs (selfplay/main.cc:68; off by default)."""
     L = lib()

@@ -318,6 +318,44 @@ def test_init_state_distribution(host):
     assert abs((komis[6.5] + komis[7.5] - (0.383 + 0.242) * hist.sum()) / hist.sum()) < 0.02
 
 
+def test_sel_mult_calibration_file(host, tmp_path):
+    """--sel_mult_calibration_file (selfplay/main.cc:64-67,71-118): per-generation thresholds replace the
+    built-in ones of MoveSelManager; comments, malformed lines and unknown fields are skipped, a missing
+    file means the defaults."""
+    import ctypes as C
+    L = host.lib()
+    L.p3host_test_move_sel_file.argtypes = [C.c_char_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                            C.c_void_p, C.c_void_p]
+    f = tmp_path / "calib.txt"
+    f.write_text("# gen 42\nv_outcome_stddev.p50=0.09\nv_outcome_stddev_adj.p80=1.4\nv_outcome_stddev_adj.p99=4.0\n"
+                 "pre_kld.p05=0.01\npre_kld.p70=0.25\nnn_mcts_diff.p70=0.2\nnn_mcts_diff.p99=0.8\n"
+                 "expected_std.n0=0.3\nexpected_std.n5=0.25\nexpected_std.nx=1\nnodot=3\nbogus.p50=7\nno equals sign\n"
+                 "pre_kld.p95=abc\n")
+
+    def sel(path, n_pre, std, kld, diff, q):
+        out, cnt = np.zeros(6, np.float32), np.zeros(5, np.int32)
+        L.p3host_test_move_sel_file(path, n_pre, std, kld, diff, q, 1.0, out.ctypes.data, cnt.ctypes.data)
+        return out, list(cnt)
+
+    o, cnt = sel(str(f).encode(), 20, 0.1, 0.03, 0.5, 0.0)
+    assert cnt == [1, 2, 2, 2, 2]
+    assert o[4] == pytest.approx(1 - 0.7 * (0.06 - 0.03) / (0.06 - 0.01), rel=1e-5)      # KLD penalty with p05 = 0.01
+    assert o[5] == pytest.approx(1 + 0.6 * (0.5 - 0.2) / (0.8 - 0.2), rel=1e-5)          # NN-MCTS bonus with p70 / p99 of the file
+    d, cnt = sel(str(tmp_path / "missing.txt").encode(), 20, 0.1, 0.03, 0.5, 0.0)
+    assert cnt == [0, 0, 0, 0, 0]
+    assert d[4] == pytest.approx(1 - 0.7 * (0.06 - 0.03) / (0.06 - 0.0001), rel=1e-5)
+    assert d[5] == pytest.approx(1 + 0.6 * (0.5 - 0.1463) / (0.65 - 0.1463), rel=1e-5)
+    # and a self-play run takes the file
+    try:
+        host.set_calibration_file(str(f))
+        host.set_groups(2)
+        st = host.selfplay_run(None, 8, 2, 0.3, default_n=8, default_k=4, selected_n=8, selected_k=4, max_moves=12,
+                               warmup_batches=1)
+    finally:
+        host.set_calibration_file("")
+    assert st.positions > 0
+
+
 def test_move_sel_manager_known_answers(host):
     """MoveSelManager::Compute (move_sel_manager.h:41-77) with the default calibration
     constants (:131-179) and self-play's flags kNnMctsBonus | kKldPenalty."""

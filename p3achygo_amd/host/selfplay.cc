@@ -1269,6 +1269,20 @@ void p3host_test_puct_scores(int node_n, float node_v, float node_v_var, const f
   PuctScoresAll(node, pp, is_root != 0, scores, vf);
 }
 
+// LeafEvaluator::EvaluateLeaf on a neutral evaluation (value 0, expected score 0), the situation of
+// cc/mcts/__tests__/leaf_evaluator_test.cc: returns init_util_est
+float p3host_test_evaluate_leaf(int color_to_move, int root_color, float root_score_est, int integral, float score_weight) {
+  p3hip_result r;
+  std::memset(&r, 0, sizeof r);
+  r.value_probs[0] = r.value_probs[1] = 0.5f;
+  r.score_probs[399] = r.score_probs[400] = 0.5f;   // E[score] = 0
+  NodePool pool;
+  TreeNode* node = pool.Create();
+  EvaluateLeaf(r, node, (Color)color_to_move, (Color)root_color, root_score_est,
+               ScoreUtilityParams{score_weight, integral ? ScoreUtilityMode::kIntegral : ScoreUtilityMode::kDirect});
+  return node->init_util_est;
+}
+
 // LeafEvaluator::ScoreUtility (leaf_evaluator.cc:125-132)
 float p3host_test_score_utility(int integral, float score_weight, float score_est, float score_stddev, float root_score_est) {
   return ScoreUtility(ScoreUtilityParams{score_weight, integral ? ScoreUtilityMode::kIntegral : ScoreUtilityMode::kDirect},

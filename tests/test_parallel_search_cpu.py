@@ -289,6 +289,19 @@ def test_puct_scorer_known_answers(L, variant):
         assert int(np.argmax(got)) == int(np.argmax(want))
 
 
+def test_leaf_evaluator_score_sign_convention(L):
+    """cc/mcts/__tests__/leaf_evaluator_test.cc (compiled out upstream, its four cases still state the
+    convention): the root's score estimate is seen from the leaf's side to move — same colour as the root
+    keeps its sign, the other colour flips it — and a neutral evaluation's utility is the score transform
+    of (0 - that)."""
+    L.p3host_test_evaluate_leaf.restype = C.c_float
+    L.p3host_test_evaluate_leaf.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.c_float]
+    BLACK, WHITE = 1, -1
+    st = lambda root: 0.5 * (2 / np.pi) * np.arctan((0 - root) / 19)
+    for c, rc, sign in ((BLACK, BLACK, 1), (BLACK, WHITE, -1), (WHITE, WHITE, 1), (WHITE, BLACK, -1)):
+        assert L.p3host_test_evaluate_leaf(c, rc, 15.0, 0, 0.5) == pytest.approx(st(sign * 15.0), abs=1e-6)
+
+
 def _score_table_entry(score_idx, stddev):
     f = np.float32
     score_mean = f(score_idx - 400 + 0.5)

@@ -25,6 +25,22 @@ void* p3host_prob_new(uint64_t seed) { return new Probability(seed); }
 void p3host_prob_free(void* p) { delete (Probability*)p; }
 float p3host_prob_uniform(void* p) { return ((Probability*)p)->Uniform(); }
 float p3host_prob_gumbel(void* p) { return ((Probability*)p)->GumbelSample(); }
+// the loops of cc/core/__tests__/probability_test.cc: float sums of n samples (kind 0 uniform, 1 Gaussian,
+// 2 Gumbel with non-finite samples counted as 0); out = mean, variance, samples outside [0, 1) (uniform)
+void p3host_prob_moments(uint64_t seed, int kind, int n, float* out) {
+  Probability p(seed);
+  float sum = 0.0f, sum_sq = 0.0f;
+  int out_of_range = 0;
+  for (int i = 0; i < n; ++i) {
+    float x = kind == 0 ? p.Uniform() : kind == 1 ? p.Gaussian() : p.GumbelSample();
+    if (kind == 0 && (x < 0.0f || x >= 1.0f)) ++out_of_range;
+    if (kind == 2 && !std::isfinite(x)) x = 0.0f;
+    sum += x;
+    sum_sq += x * x;
+  }
+  const float mean = sum / n;
+  out[0] = mean; out[1] = sum_sq / n - mean * mean; out[2] = (float)out_of_range;
+}
 
 // ---- symmetry --------------------------------------------------------------------------
 int p3host_transform_index(int sym, int idx, int n) { return TransformIndex((Symmetry)sym, idx, n); }

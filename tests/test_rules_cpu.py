@@ -179,6 +179,36 @@ def test_prng_known_answers(host):
     L.p3host_prob_free(p)
 
 
+def test_probability_moments_and_prng_determinism(host):
+    """cc/core/__tests__/probability_test.cc (uniform / Gaussian / Gumbel sample moments over 10^6 draws from
+    seed 42, the file's tolerances) and rand_test.cc (same seeds give the same streams through every
+    constructor arity; RandRange stays in range)."""
+    import ctypes as C
+    L = host.lib()
+    L.p3host_prob_moments.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+    out = np.zeros(3, np.float32)
+    L.p3host_prob_moments(42, 0, 1000000, out.ctypes.data)
+    assert out[2] == 0 and out[0] == pytest.approx(0.5, rel=0.002) and out[1] == pytest.approx(1 / 12, rel=0.002)
+    L.p3host_prob_moments(42, 1, 1000000, out.ctypes.data)
+    assert abs(out[0]) <= 0.005 and out[1] == pytest.approx(1.0, rel=0.005)
+    L.p3host_prob_moments(42, 2, 1000000, out.ctypes.data)
+    assert out[0] == pytest.approx(0.5772156649, rel=0.007) and out[1] == pytest.approx(np.pi ** 2 / 6, rel=0.01)
+    L.p3host_prng_new.restype = C.c_void_p
+    L.p3host_prng_new.argtypes = [C.c_uint64] * 4
+    for seeds in ((7, 0, 0, 0), (11, 12, 0, 0), (17, 13, 4, 5), (0, 1, 2, 3)):
+        a, b = L.p3host_prng_new(*seeds), L.p3host_prng_new(*seeds)
+        hi0, lo0, hi1, lo1 = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        for _ in range(4):
+            L.p3host_prng_next128(C.c_void_p(a), C.byref(hi0), C.byref(lo0))
+            L.p3host_prng_next128(C.c_void_p(b), C.byref(hi1), C.byref(lo1))
+            assert (hi0.value, lo0.value) == (hi1.value, lo1.value)
+        L.p3host_prng_free(C.c_void_p(a)); L.p3host_prng_free(C.c_void_p(b))
+    h = L.p3host_prng_new(0, 1, 2, 3)
+    for lo, hi in ((0, 5), (-80, -40), (10, 50), (-40, 30)):
+        assert lo <= L.p3host_rand_range(C.c_void_p(h), lo, hi) < hi
+    L.p3host_prng_free(C.c_void_p(h))
+
+
 def test_superko_and_ko(host):
     """Positional superko (board.cc:617-621): the ko recapture recreates an earlier
     whole-board position -> kRepeatedPosition; after an exchange elsewhere the same point is

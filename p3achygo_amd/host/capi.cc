@@ -530,6 +530,15 @@ void p3host_test_move_sel_file(const char* path, int n_pre, float std_dev, float
   out[0] = r.modifier; out[1] = r.sel_bonus; out[2] = r.sel_penalty; out[3] = r.sel_q_adjust;
   out[4] = r.sel_kld_penalty; out[5] = r.sel_nn_mcts_bonus;
 }
+// any flag set, thresholds from a calibration file ("" = none); out = the twelve MoveSelResult fields in order
+void p3host_test_move_sel_ex(unsigned flags, const char* path, int n_pre, float std_dev, float pre_kld, float nn_mcts_diff,
+                             float q, float scale, float* out) {
+  MoveSelManager m(flags, ParseCalibrationFile(path ? path : ""));
+  const MoveSelResult r = m.Compute(n_pre, std_dev, pre_kld, nn_mcts_diff, q, scale);
+  const float v[12] = {r.modifier, r.modifier_unscaled, r.sel_bonus, r.sel_penalty, r.sel_std_bonus, r.sel_std_penalty,
+                       r.sel_kld_bonus, r.sel_kld_penalty, r.sel_nn_mcts_bonus, r.sel_q_adjust, r.std_adj, r.std_adj_att};
+  std::memcpy(out, v, sizeof v);
+}
 void p3host_test_move_sel(int n_pre, float std_dev, float pre_kld, float nn_mcts_diff, float q, float scale, float* out) {
   SelMultCalibration cal;
   MoveSelManager m(kNnMctsBonus | kKldPenalty, cal);

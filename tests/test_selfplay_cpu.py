@@ -356,6 +356,66 @@ def test_sel_mult_calibration_file(host, tmp_path):
     assert st.positions > 0
 
 
+def test_move_sel_manager_reference_cases(host, tmp_path):
+    """All 14 cases of cc/selfplay/__tests__/move_sel_manager_test.cc, with its MakeCalibration() thresholds
+    handed over as a calibration file."""
+    import ctypes as C
+    L = host.lib()
+    L.p3host_test_move_sel_ex.argtypes = [C.c_uint, C.c_char_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, C.c_void_p]
+    SB, SP, KB, KP, NM = 1, 2, 4, 8, 16
+    base = ("v_outcome_stddev_adj.p01=0.02\nv_outcome_stddev_adj.p50=0.64\nv_outcome_stddev_adj.p80=1.52\n"
+            "v_outcome_stddev_adj.p99=4.96\nnn_mcts_diff.p70=0.15\nnn_mcts_diff.p99=0.65\n" +
+            "".join(f"expected_std.n{n}=0.16\n" for n in range(0, 201, 5)))
+    files = {}
+    for name, extra in (("base", ""), ("kldb", "pre_kld.p70=0.1\npre_kld.p95=0.5\n"), ("kldp", "pre_kld.p05=0.001\n")):
+        files[name] = tmp_path / (name + ".txt")
+        files[name].write_text(base + extra)
+    K = ("modifier", "modifier_unscaled", "sel_bonus", "sel_penalty", "sel_std_bonus", "sel_std_penalty", "sel_kld_bonus",
+         "sel_kld_penalty", "sel_nn_mcts_bonus", "sel_q_adjust", "std_adj", "std_adj_att")
+
+    def compute(flags, cal, n_pre, std, kld, diff, q, scale):
+        out = np.zeros(12, np.float32)
+        L.p3host_test_move_sel_ex(flags, str(files[cal]).encode() if cal else b"", n_pre, std, kld, diff, q, scale,
+                                  out.ctypes.data)
+        return dict(zip(K, (float(x) for x in out)))
+    ap = lambda x: pytest.approx(x, rel=1e-5)
+    r = compute(SB | SP, None, 32, 0.15, 0, 0, 0, 1)                      # uncalibrated: std_adj = 0 => modifier 1
+    assert r["std_adj"] == 0 and r["std_adj_att"] == 0 and r["sel_std_bonus"] == ap(1) and r["sel_std_penalty"] == ap(1)
+    assert r["modifier"] == ap(1)
+    r = compute(SB | SP, "base", 128, 0.16, 0, 0, 0, 1)                   # neutral position
+    assert r["std_adj"] == ap(1) and r["sel_std_bonus"] == ap(1) and r["sel_std_penalty"] == ap(1) and r["modifier"] == ap(1)
+    r = compute(SB | SP, "base", 128, 0.48, 0, 0, 0, 1)                   # high std_adj => bonus
+    assert r["std_adj"] == ap(3) and r["std_adj_att"] == ap(3) and r["sel_std_bonus"] > 1 and r["sel_std_penalty"] == ap(1)
+    assert r["modifier"] > 1 and r["sel_std_bonus"] == pytest.approx(1 + 0.5 * (3.0 - 1.52) / (4.96 - 1.52), rel=1e-4)
+    r = compute(SB | SP, "base", 128, 0.016, 0, 0, 0, 1)                  # low std_adj => penalty
+    assert r["std_adj"] < 0.64 and r["sel_std_penalty"] < 1 and r["sel_std_bonus"] == ap(1) and r["modifier"] < 1
+    lo, hi = compute(SB | SP, "base", 5, 0.48, 0, 0, 0, 1), compute(SB | SP, "base", 128, 0.48, 0, 0, 0, 1)
+    assert lo["std_adj_att"] < hi["std_adj_att"] and lo["modifier"] < hi["modifier"]       # low n_pre attenuates
+    con, dec = compute(SB | SP, "base", 128, 0.48, 0, 0, 0, 1), compute(SB | SP, "base", 128, 0.48, 0, 0, 0.95, 1)
+    assert dec["sel_q_adjust"] < con["sel_q_adjust"] and dec["sel_bonus"] < con["sel_bonus"]   # decisive position
+    r = compute(SB, "base", 128, 0.016, 0, 0, 0, 1)                       # flag off: computed, not applied
+    assert r["sel_std_penalty"] < 1 and r["sel_penalty"] == ap(1) and r["modifier"] == ap(1)
+    r = compute(SB | SP, "base", 128, 0.48, 0, 0, 0, 0)                   # scale factor 0
+    assert r["modifier"] == ap(1) and r["modifier_unscaled"] > 1
+    both, std, kld = (compute(f, "kldb", 128, 0.48, 0.3, 0, 0, 1) for f in (SB | KB, SB, KB))   # bonus = max, not product
+    assert both["sel_std_bonus"] > 1 and both["sel_kld_bonus"] > 1
+    assert both["sel_bonus"] == pytest.approx(max(std["sel_bonus"], kld["sel_bonus"]), rel=1e-3)
+    assert both["sel_bonus"] < std["sel_bonus"] * kld["sel_bonus"]
+    both, std, kld = (compute(f, "kldp", 128, 0.016, 0.005, 0, 0, 1) for f in (SP | KP, SP, KP))   # penalty = min
+    assert both["sel_std_penalty"] < 1 and both["sel_kld_penalty"] < 1
+    assert both["sel_penalty"] == pytest.approx(min(std["sel_penalty"], kld["sel_penalty"]), rel=1e-3)
+    assert both["sel_penalty"] > std["sel_penalty"] * kld["sel_penalty"]
+    r = compute(NM, "base", 128, 0, 0, 0.5, 0, 1)                         # NN-MCTS bonus: 1 + 0.6 * 0.35 / 0.5
+    assert r["sel_nn_mcts_bonus"] == pytest.approx(1.42, rel=1e-4) and r["sel_bonus"] > 1 and r["modifier"] > 1
+    r = compute(NM, "base", 0, 0, 0, 0, 0, 1)                             # uninitialised root
+    assert r["sel_nn_mcts_bonus"] == ap(1) and r["modifier"] == ap(1)
+    r = compute(NM, "base", 128, 0, 0, 0.05, 0, 1)                        # below the lower bound
+    assert r["sel_nn_mcts_bonus"] == ap(1) and r["modifier"] == ap(1)
+    both, nm, kld = (compute(f, "kldb", 128, 0, 0.3, 0.5, 0, 1) for f in (NM | KB, NM, KB))
+    assert both["sel_bonus"] == pytest.approx(max(nm["sel_bonus"], kld["sel_bonus"]), rel=1e-3)
+
+
 def test_move_sel_manager_known_answers(host):
     """MoveSelManager::Compute (move_sel_manager.h:41-77) with the default calibration
     constants (:131-179) and self-play's flags kNnMctsBonus | kKldPenalty."""

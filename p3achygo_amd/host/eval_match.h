@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <fstream>
 #include <memory>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -136,9 +137,7 @@ inline GumbelParams MakeGumbelParams(const EvalPlayerConfig& c) {   // eval.cc:2
 // lines skipped, every PlayerSearchConfig field by its name, unknown keys ignored, enum-valued fields fall
 // back as MakeSearchParams does (player_config.cc:56-95: an unknown q_fn is virtual_loss, the others their
 // defaults).  Returns false only when the file cannot be opened or a number does not parse.
-inline bool ParsePlayerConfig(const std::string& path, EvalPlayerConfig* cfg, std::string* err) {
-  std::ifstream in(path);
-  if (!in) { if (err) *err = "cannot open " + path; return false; }
+inline bool ParsePlayerConfigStream(std::istream& in, EvalPlayerConfig* cfg, std::string* err) {
   auto trim = [](std::string x) {
     const size_t b = x.find_first_not_of(" \t\r\n");
     if (b == std::string::npos) return std::string();
@@ -202,6 +201,18 @@ inline bool ParsePlayerConfig(const std::string& path, EvalPlayerConfig* cfg, st
     return false;
   }
   return true;
+}
+inline bool ParsePlayerConfig(const std::string& path, EvalPlayerConfig* cfg, std::string* err) {
+  std::ifstream in(path);
+  if (!in) { if (err) *err = "cannot open " + path; return false; }
+  return ParsePlayerConfigStream(in, cfg, err);
+}
+// The per-player command-line flags of eval/main.cc (--cur_n, --cand_use_puct_v, ...; ApplyCur/
+// CandCommandLineFlags, main.cc:146-246) override the config file: here the same "key: value" lines,
+// applied after the file.
+inline bool ApplyPlayerConfigText(const std::string& text, EvalPlayerConfig* cfg, std::string* err) {
+  std::istringstream in(text);
+  return ParsePlayerConfigStream(in, cfg, err);
 }
 
 class EvalGame {

@@ -907,6 +907,7 @@ static int g_eval_mode = 0, g_eval_qfn = 2, g_eval_nfn = 1, g_eval_collision = 0
 static int g_eval_descent = 0, g_eval_mcgs = 0, g_eval_cache_per_game = 256;
 static float g_eval_max_o = 1.0f, g_eval_bias_lambda = 0.0f, g_eval_bias_alpha = 0.8f;
 static std::string g_eval_cur_cfg, g_eval_cand_cfg, g_eval_recorder_dir, g_eval_res_path;
+std::string g_eval_cur_cli, g_eval_cand_cli;   // --cur_* / --cand_* flags as "key: value" lines
 // Parallel-search knobs of subsequent p3host_eval_match calls (defaults = player_config.h:76-108:
 // concurrent rounds, virtual_loss_soft, virtual_visit, abort, noop).
 void p3host_eval_set_search(int mode, int q_fn, int n_fn, int collision, int detector) {
@@ -930,6 +931,11 @@ void p3host_eval_set_paths(const char* cur_config, const char* cand_config, cons
   g_eval_res_path = res_write_path ? res_write_path : "";
 }
 
+extern "C" void p3host_eval_set_player_flags(const char* cur, const char* cand) {
+  g_eval_cur_cli = cur ? cur : "";
+  g_eval_cand_cli = cand ? cand : "";
+}
+
 static bool MakeEvalPlayerConfigs(int visits_per_move, int leaves_per_round, EvalPlayerConfig pc[2], char* err) {
   EvalPlayerConfig base;
   base.n = visits_per_move;
@@ -949,6 +955,9 @@ static bool MakeEvalPlayerConfigs(int visits_per_move, int leaves_per_round, Eva
   std::string e;
   if (!g_eval_cur_cfg.empty() && !ParsePlayerConfig(g_eval_cur_cfg, &pc[0], &e)) { if (err) snprintf(err, 256, "cur config: %s", e.c_str()); return false; }
   if (!g_eval_cand_cfg.empty() && !ParsePlayerConfig(g_eval_cand_cfg, &pc[1], &e)) { if (err) snprintf(err, 256, "cand config: %s", e.c_str()); return false; }
+  // per-player command-line flags win over the file (eval/main.cc:146-246, 299-320)
+  if (!g_eval_cur_cli.empty() && !ApplyPlayerConfigText(g_eval_cur_cli, &pc[0], &e)) { if (err) snprintf(err, 256, "cur flags: %s", e.c_str()); return false; }
+  if (!g_eval_cand_cli.empty() && !ApplyPlayerConfigText(g_eval_cand_cli, &pc[1], &e)) { if (err) snprintf(err, 256, "cand flags: %s", e.c_str()); return false; }
   return true;
 }
 

@@ -303,6 +303,14 @@ def eval_set_paths(cur_config: str = "", cand_config: str = "", recorder_dir: st
     L.p3host_eval_set_paths(cur_config.encode(), cand_config.encode(), recorder_dir.encode(), res_write_path.encode())
 
 
+def eval_set_player_flags(cur: str = "", cand: str = "") -> None:
+    """The per-player command-line flags of eval/main.cc (--cur_n, --cand_use_puct_v, ...) of subsequent
+    matches, as "key: value" lines; they override the player's config file (main.cc:146-246)."""
+    L = lib()
+    L.p3host_eval_set_player_flags.argtypes = [C.c_char_p, C.c_char_p]
+    L.p3host_eval_set_player_flags(cur.encode(), cand.encode())
+
+
 def eval_match(cur_weights: str | None, cand_weights: str | None, num_games: int, visits_per_move: int = 128,
                leaves_per_round: int = 8, max_moves: int = 600, num_threads: int = 8, seed: int = 1,
                device: int = 0, engine_lib: str | None = None) -> EvalStats:

@@ -366,6 +366,16 @@ def test_eval_match_player_configs_cover_every_search_path(built, tmp_path):
         assert a.moves == 4 * 20 and a.visits >= 4 * 10 * (16 + 24) * 0.8   # ten moves each side, the files' budgets
         res.append((a.visits, a.positions))
     assert res[0] != res[1]
+    # a player's command-line flags win over its file (eval/main.cc:146-246): --cand_n 4 against the file's 16
+    try:
+        host_api.eval_set_paths(cur_config=str(cur), cand_config=str(cand))
+        host_api.eval_set_player_flags(cand="n: 4\n")
+        c = host_api.eval_match(None, None, num_games=4, visits_per_move=999, leaves_per_round=9, max_moves=20,
+                                num_threads=2, seed=11)
+    finally:
+        host_api.eval_set_paths()
+        host_api.eval_set_player_flags()
+    assert c.moves == 4 * 20 and c.visits < res[1][0] - 4 * 10 * 8
 
 
 def test_eval_match_cache_sgf_and_result_file(built, tmp_path):

@@ -109,6 +109,46 @@ def hbm_traffic(kernel_name, positions):
     return None
 
 
+def measure_hbm_traffic(model, batch, kernel_prefix):
+    """HBM bytes per launch of the dominant kernel, measured now: two child runs of three forward passes
+    under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes;
+    the counters need the profiler around a whole process, hence children of this one).  gfx950
+    correction: every read of these kernels is a 16-byte-per-lane access, which FETCH_SIZE tallies at
+    half its bytes.  Returns (bytes, detail) or (None, reason)."""
+    import csv, glob, shutil, subprocess
+    if batch != 1024:
+        return None, "the counter run uses batches of 1024"
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "already running under a profiler"
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="p3pmc_")
+        try:
+            subprocess.run([exe, "--output-format", "csv", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--",
+                            sys.executable, os.path.join(ROOT, "tools", "gpu_run_forward.py"), "3", model],
+                           cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()),
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            xs = []
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for r in csv.DictReader(f):
+                        if r["Counter_Name"] == counter and r["Kernel_Name"].startswith(kernel_prefix):
+                            xs.append(float(r["Counter_Value"]))
+            if not xs:
+                return None, f"no {counter} rows for {kernel_prefix}"
+            vals[counter] = sum(xs) / len(xs)
+        except Exception as ex:   # noqa: BLE001
+            return None, f"{counter} pass failed: {ex!r}"[:200]
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    total = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return total, {"fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
+                   "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two child runs of 3 forward passes; reads = 2 x FETCH_SIZE (gfx950 half-count of 16-byte accesses); mean over the kernel's launches"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +158,7 @@ def main():
     ap.add_argument("--groups", type=int, default=DEFAULT_GROUPS, help="game groups (engine instances / HIP streams) per GPU")
     ap.add_argument("--model", default=MODEL)
     ap.add_argument("--engine-steps", type=int, default=200, help="timed steps of the engine-only leg")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic measurement (two rocprofv3 --pmc child runs)")
     ap.add_argument("--ladder-budget", type=int, default=LADDER_BUDGET,
                     help="ladder read-out work bound of the self-play host (0 = reference-exact, the default; "
                          "> 0 = the opt-in throughput mode, hits are reported)")
@@ -205,6 +246,15 @@ def main():
         if prof:
             roof["algorithmic_bytes_per_launch"] = prof["algorithmic_bytes_per_launch"]
             roof["traffic_source"] = "recorded: " + prof["source"]
+        if not args.no_pmc:
+            prefix = "void p3::k_block<" if kname.startswith("k_block") else "void p3::k_lconv<3,"
+            live, detail = measure_hbm_traffic(args.model, args.batch, prefix)
+            if live is not None:
+                roof["traffic"] = live
+                roof["traffic_source"] = "measured in this run: " + detail["how"]
+                roof["traffic_counters"] = {k: detail[k] for k in ("fetch_size_kib_raw", "write_size_kib")}
+            else:
+                roof["traffic_live_unavailable"] = detail
         roof["launch_contents"] = ("residual blocks + the 1x1 convs of the neighbouring broadcast blocks (HBM-bound, "
                                    "4.9 % of the FLOPs); blocks_only = the same launches with those convs as their own "
                                    "launches (P3HIP_NO_BFUSE=1: slower forward pass, comparable with earlier rounds)")

@@ -228,6 +228,7 @@ struct p3hip_engine {
   _Float16 *d_x = nullptr, *d_t = nullptr, *d_u = nullptr;
 #ifdef P3_DIAG
   unsigned long long* d_stamps = nullptr;   // diagnostic build: k_block phase stamps of one launch (P3DIAG_LAUNCH)
+  unsigned long long* d_spans = nullptr;    // and every workgroup's entry / per-position / exit times of that launch
   int launch_index = 0;
 #endif
   _Float16* d_s = nullptr;   // nbt trunks: the block kernel's inner-stream scratch (t and u carry the broadcast blocks' tensors)
@@ -539,6 +540,11 @@ p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
     static const int stagger_env = getenv("P3HIP_STAGGER") ? atoi(getenv("P3HIP_STAGGER")) : -1;
     const bool long_launch = npos >= 3 * e->n_cu * (e->wf.C == 256 || e->c128_wg8 ? 1 : 2);
     a.stagger = stagger_env >= 0 ? stagger_env : ((a.head || a.tail) && long_launch ? 10000 : 0);
+    // two 4-wave workgroups per CU and at least two positions each: they take turns at the higher wave
+    // priority (kernels.h; b12c128btl3 forward -3.5 %, b8c128nbt -2.5 % at 1024 positions, nothing at 512 and
+    // below; profiles/r02_c128_pair_turns.txt).  P3HIP_NO_PAIR_TURNS=1 leaves the priorities alone.
+    static const bool no_pair_turns = getenv("P3HIP_NO_PAIR_TURNS") != nullptr;
+    a.pair_turns = !no_pair_turns && e->wf.C == 128 && !e->c128_wg8 && npos >= 4 * e->n_cu;
   }
   for (int b = 0; b < count; ++b) {
     const BlockPlan& bp = e->blocks[first + b];
@@ -620,6 +626,9 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
         static const int which = getenv("P3DIAG_LAUNCH") ? atoi(getenv("P3DIAG_LAUNCH")) : 1;
         constexpr size_t bytes = (size_t)p3::kStampWgs * 8 * p3::kStampSections * p3::kStampSlots * 8;
         if (!e->d_stamps && hipMalloc((void**)&e->d_stamps, bytes) == hipSuccess) hipMemset(e->d_stamps, 0, bytes);
+        constexpr size_t span_bytes = (size_t)p3::kSpanWgs * p3::kSpanSlots * 8;
+        if (!e->d_spans && hipMalloc((void**)&e->d_spans, span_bytes) == hipSuccess) hipMemset(e->d_spans, 0, span_bytes);
+        a.spans = (e->launch_index == which) ? e->d_spans : nullptr;
         a.stamps = (e->launch_index++ == which) ? e->d_stamps : nullptr;
       }
 #endif
@@ -929,6 +938,12 @@ int p3hip_debug_block_stamps(p3hip_engine* e, unsigned long long* out, int n) {
   constexpr int total = p3::kStampWgs * 8 * p3::kStampSections * p3::kStampSlots;
   hipStreamSynchronize(e->stream);
   return hipMemcpy(out, e->d_stamps, (size_t)(n < total ? n : total) * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+int p3hip_debug_block_spans(p3hip_engine* e, unsigned long long* out, int n) {
+  if (!e->bind() || !e->d_spans) return 1;
+  constexpr int total = p3::kSpanWgs * p3::kSpanSlots;
+  hipStreamSynchronize(e->stream);
+  return hipMemcpy(out, e->d_spans, (size_t)(n < total ? n : total) * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
 }
 #endif
 

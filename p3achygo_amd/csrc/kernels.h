@@ -52,15 +52,24 @@ struct BlockArgs {
   // start-up stagger (shader-clock cycles per step, 0 = none): workgroup b begins (b / 8) % 8 steps late,
   // so the CUs of an XCD are not all in their HBM-bound phases (head / tail / residual traffic) at once
   int stagger;
+  // 4-wave form, two workgroups per CU (grid = 2 x CUs: blocks b and b + grid/2 share a CU): the SIMD arbiter
+  // serves the older workgroup's waves first, so at equal priority the second workgroup of every CU falls behind
+  // and finishes its positions alone on the CU.  With pair_turns the two take turns at the higher wave priority,
+  // one position each (the second workgroup first), and finish together.
+  int pair_turns;
 #ifdef P3_DIAG
   // diagnostic build only (make diag): lane 0 of every wave of workgroups 0..7 stores s_memtime at
   // the phase boundaries of its second position: stamps[((wg * 8 + wave) * 8 + section) * 32 + k],
   // section = block index (0..5), 6 = head, 7 = tail.  Never read by the kernel.
   unsigned long long* stamps;
+  // spans[wg * 16 + k], every workgroup (up to 512), wave 0: k = 0 kernel entry, 1 ring ready, 2 + p end of
+  // the workgroup's position p (p < 5), 7 exit in shader-clock ticks (s_memtime; not comparable across XCDs);
+  // [8 + k] the same instants on the 100 MHz device-wide counter (s_memrealtime)
+  unsigned long long* spans;
 #endif
 };
 #ifdef P3_DIAG
-constexpr int kStampWgs = 8, kStampSections = 8, kStampSlots = 32;
+constexpr int kStampWgs = 8, kStampSections = 8, kStampSlots = 32, kSpanWgs = 512, kSpanSlots = 16;
 #endif
 
 struct InitArgs {

@@ -63,8 +63,16 @@ namespace p3 {
       a.stamps[((blockIdx.x * 8 + (threadIdx.x >> 6)) * kStampSections + (section)) * kStampSlots + (k)] = \
           __builtin_amdgcn_s_memtime();                                                                   \
   } while (0)
+#define P3_SPAN(k)                                                                        \
+  do {                                                                                    \
+    if (a.spans && blockIdx.x < kSpanWgs && threadIdx.x == 0 && (k) < 8) {                \
+      a.spans[blockIdx.x * kSpanSlots + (k)] = __builtin_amdgcn_s_memtime();              \
+      a.spans[blockIdx.x * kSpanSlots + 8 + (k)] = __builtin_amdgcn_s_memrealtime();      \
+    }                                                                                     \
+  } while (0)
 #else
 #define P3_STAMP(section, k) do {} while (0)
+#define P3_SPAN(k) do {} while (0)
 #endif
 
 template <int C, int CB, int KIND, int L, int NW = 8, bool BC = false>
@@ -78,6 +86,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
   constexpr uint32_t kRingOff = G::ACT_BYTES;
   static_assert(C / CB == 2, "two input slices / two output passes");
 
+  P3_SPAN(0);
   act_zero<G>(smem);
   if (BC && a.stagger > 0) {
     const int key = (blockIdx.x >> 3) & 7;   // consecutive block ids go to different XCDs: this is the CU slot inside one
@@ -87,11 +96,16 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
   Ring<T::RS, NW, G::RD> ring;
   ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
   lds_barrier();
+  P3_SPAN(1);
 
   int npos_done = 0;
   for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS, ++npos_done) {
     EpiOut16<NT> A1;   // activated reduce input, channel half 1, made by the previous block's expand
     const bool head = BC && a.head, tail = BC && a.tail;
+    if (NW == 4 && a.pair_turns) {   // whose turn at the higher priority (kernels.h)
+      if ((blockIdx.x >= gridDim.x / 2) != (bool)(npos_done & 1)) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     if (head) {
       // ---- conv_last of the broadcast block before the run: x' = x + W . z ----------------------
       // Both K slices of z are requested together (one exposed latency).  Pass 0 runs slice 0 then
@@ -309,8 +323,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       epilogue_store16_mish<NT>(acc, tr, a.tout);
       P3_STAMP(7, 12);
     }
+    P3_SPAN(2 + npos_done < 7 ? 2 + npos_done : 6);
   }
   ring_drain();
+  P3_SPAN(7);
 }
 
 // =======================================================================================

@@ -194,14 +194,16 @@ def test_concurrent_load_and_get(built, weight_files):
     eng.close()
 
 
-def test_full_batch_properties_b12c256btl3(built, weight_files):
+@pytest.mark.parametrize("name", ["b12c256btl3", "b12c128btl3", "b8c128nbt"])
+def test_full_batch_properties(built, weight_files, name):
     """BASELINE size (1024 positions): size-independent properties — every probability
     vector sums to 1, results do not depend on batch position or batch size (a position
     evaluated alone equals the same position inside the full batch, bit for bit), and a
-    strided sample agrees with the oracle."""
+    strided sample agrees with the oracle.  At this size the C = 128 launches run two
+    workgroups per CU taking turns at the higher wave priority (BlockArgs::pair_turns); the
+    single-position run does not."""
     from oracle import oracle
     from p3achygo_amd import engine, features
-    name = "b12c256btl3"
     base = features.random_positions(64, seed=31, n_games=16)
     pos = np.tile(base, 16)
     eng = engine.HipEngine(weight_files(name, randomize=False), 1024)

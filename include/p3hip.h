@@ -122,6 +122,30 @@ int p3hip_get_slot(p3hip_engine* e, int slot, p3hip_result* out);
 int p3hip_get_ownership(p3hip_engine* e, int slot, float out[P3HIP_NUM_LOCS]);
 const char* p3hip_last_error(const p3hip_engine* e);
 
+/* ---- on-device NN cache (extension; the reference caches on the host, above the engine) ----------
+ * The reference's NNInterface keeps an LRU cache of NNInferResults per worker thread, keyed by
+ * NNKey{color to move, board hash, last moves, komi}; a hit returns the stored result without touching the
+ * engine, a miss evaluates under a random symmetry and stores the un-rotated result
+ * (cc/nn/nn_interface.cc:93-132, cc/core/lru_cache.h:17-64).  With 288 GB of HBM the table can live beside the
+ * engine instead: one table for all workers and games, looked up and filled by the run itself.
+ *   p3hip_cache_enable      once after p3hip_create: 2^log2_entries entries of 13.7 KB (key, symmetry, the
+ *                           whole result record) in HBM; each key probes 8 consecutive entries, the least
+ *                           recently used of them is replaced.
+ *   p3hip_load_slot_keyed   LoadBatch with the position's 128-bit key (any digest of the reference's NNKey;
+ *                           0/0 = do not cache) and the symmetry (0..7) the features were rotated by.
+ *   p3hip_run               evaluates only the keys the table does not hold, serves the rest from HBM, stores
+ *                           what it evaluated.  Two slots with the same new key in one run are both evaluated.
+ *   p3hip_get_slot_keyed    GetBatch plus the symmetry of the returned result — the stored one on a hit, which
+ *                           the caller undoes exactly as the reference's GetBatch(thread, sym) would have when
+ *                           the entry was made — and whether it came from the table.
+ * Slots loaded with p3hip_load_slot are evaluated and never cached.  p3hip_cache_stats: lookups, hits,
+ * stored entries, table entries. */
+int p3hip_cache_enable(p3hip_engine* e, int log2_entries);
+int p3hip_load_slot_keyed(p3hip_engine* e, int slot, const p3hip_features* f, uint64_t key_lo, uint64_t key_hi,
+                          int symmetry);
+int p3hip_get_slot_keyed(p3hip_engine* e, int slot, p3hip_result* out, int* symmetry, int* from_cache);
+int p3hip_cache_stats(const p3hip_engine* e, uint64_t out[4]);
+
 /* ---- measurement / test hooks (not part of the reference surface) ------------------ */
 
 /* Device-resident benchmark step: runs the forward pass on whatever is already staged in

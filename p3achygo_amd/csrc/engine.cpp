@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <unordered_set>
 #include <string>
 #include <vector>
 
@@ -237,6 +238,29 @@ struct p3hip_engine {
   float* h_out = nullptr;  // pinned [batch][kResultFloats]
   p3::SlotStates slots;   // dirty flags + slot -> dense row of the last run (slot_state.h)
   int last_n = 0;
+
+  // on-device NN cache (p3hip_cache_enable): the table, the per-slot keys as loaded, and the per-run lists
+  struct DeviceCache {
+    bool on = false;
+    unsigned mask = 0, run = 0;
+    unsigned long long* d_tkeys = nullptr;
+    unsigned* d_tmeta = nullptr;
+    float* d_tvals = nullptr;
+    p3::CacheKey* h_slot_keys = nullptr;   // [batch] by slot (plain memory, written by load_slot_keyed)
+    p3::CacheKey *h_keys = nullptr, *d_keys = nullptr;   // [batch] by row of the run (pinned / device)
+    int *h_hit = nullptr, *d_hit = nullptr, *h_victim = nullptr, *d_victim = nullptr;
+    int *h_lists = nullptr, *d_lists = nullptr;          // [5][batch]: miss rows, hit entries, insert rows, insert src, insert entries
+    unsigned *h_sym = nullptr, *d_sym = nullptr;         // [batch] symmetry of the result in out row r
+    unsigned char* d_feats2 = nullptr;                   // features of the misses, dense
+    std::vector<int> out_row;                            // row of the run -> row of d_out / h_out
+    std::vector<unsigned char> was_hit;                  // by row of the run
+    unsigned long long lookups = 0, hits = 0, inserts = 0;
+  } cache;
+  // row of d_out / h_out that holds `slot`'s result (-1: not evaluated by the last run)
+  int out_row_of(int slot) const {
+    const int row = slots.row(slot);
+    return (row >= 0 && cache.on) ? cache.out_row[row] : row;
+  }
 
   bool check(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
@@ -732,6 +756,17 @@ void p3hip_destroy(p3hip_engine* e) {
   if (e->stream) hipStreamSynchronize(e->stream);
   hipFree(e->d_arena); hipFree(e->d_feats); hipFree(e->d_x); hipFree(e->d_t); hipFree(e->d_u); hipFree(e->d_s);
   hipFree(e->d_hp); hipFree(e->d_out);
+  {
+    auto& c = e->cache;
+    hipFree(c.d_tkeys); hipFree(c.d_tmeta); hipFree(c.d_tvals); hipFree(c.d_keys); hipFree(c.d_hit); hipFree(c.d_victim);
+    hipFree(c.d_lists); hipFree(c.d_sym); hipFree(c.d_feats2);
+    if (c.h_keys) hipHostFree(c.h_keys);
+    if (c.h_hit) hipHostFree(c.h_hit);
+    if (c.h_victim) hipHostFree(c.h_victim);
+    if (c.h_lists) hipHostFree(c.h_lists);
+    if (c.h_sym) hipHostFree(c.h_sym);
+    delete[] c.h_slot_keys;
+  }
   if (e->h_feats) hipHostFree(e->h_feats);
   if (e->h_feats_compact) hipHostFree(e->h_feats_compact);
   if (e->h_out) hipHostFree(e->h_out);
@@ -750,8 +785,52 @@ const char* p3hip_last_error(const p3hip_engine* e) { return e->err.c_str(); }
 int p3hip_load_slot(p3hip_engine* e, int slot, const p3hip_features* f) {
   if (slot < 0 || slot >= e->batch) return 1;
   memcpy(e->h_feats + (size_t)slot * kFeatBytes, f, kFeatBytes);
+  if (e->cache.on) e->cache.h_slot_keys[slot] = p3::CacheKey{0, 0, 0};   // no key: evaluated, never cached
   e->slots.loaded(slot);
   return 0;
+}
+
+int p3hip_load_slot_keyed(p3hip_engine* e, int slot, const p3hip_features* f, uint64_t key_lo, uint64_t key_hi, int symmetry) {
+  if (slot < 0 || slot >= e->batch) return 1;
+  if (symmetry < 0 || symmetry > 7) return 1;
+  memcpy(e->h_feats + (size_t)slot * kFeatBytes, f, kFeatBytes);
+  if (e->cache.on) e->cache.h_slot_keys[slot] = p3::CacheKey{key_lo, key_hi, (unsigned long long)symmetry};
+  e->slots.loaded(slot);
+  return 0;
+}
+
+int p3hip_cache_enable(p3hip_engine* e, int log2_entries) {
+  if (!e->bind()) return 1;
+  if (e->cache.on) { e->err = "cache already enabled"; return 1; }
+  if (log2_entries < 4 || log2_entries > 26) { e->err = "cache size: 2^4 .. 2^26 entries"; return 1; }
+  auto& c = e->cache;
+  const size_t cap = (size_t)1 << log2_entries, B = (size_t)e->batch;
+  bool ok = e->check(hipMalloc((void**)&c.d_tkeys, cap * 16), "hipMalloc cache keys") &&
+            e->check(hipMalloc((void**)&c.d_tmeta, cap * 4), "hipMalloc cache meta") &&
+            e->check(hipMalloc((void**)&c.d_tvals, cap * p3::kOutStride * 4), "hipMalloc cache records") &&
+            e->check(hipMalloc((void**)&c.d_keys, B * sizeof(p3::CacheKey)), "hipMalloc") &&
+            e->check(hipMalloc((void**)&c.d_hit, B * 4), "hipMalloc") && e->check(hipMalloc((void**)&c.d_victim, B * 4), "hipMalloc") &&
+            e->check(hipMalloc((void**)&c.d_lists, 5 * B * 4), "hipMalloc") && e->check(hipMalloc((void**)&c.d_sym, B * 4), "hipMalloc") &&
+            e->check(hipMalloc((void**)&c.d_feats2, B * kFeatBytes), "hipMalloc") &&
+            e->check(hipHostMalloc((void**)&c.h_keys, B * sizeof(p3::CacheKey), hipHostMallocDefault), "hipHostMalloc") &&
+            e->check(hipHostMalloc((void**)&c.h_hit, B * 4, hipHostMallocDefault), "hipHostMalloc") &&
+            e->check(hipHostMalloc((void**)&c.h_victim, B * 4, hipHostMallocDefault), "hipHostMalloc") &&
+            e->check(hipHostMalloc((void**)&c.h_lists, 5 * B * 4, hipHostMallocDefault), "hipHostMalloc") &&
+            e->check(hipHostMalloc((void**)&c.h_sym, B * 4, hipHostMallocDefault), "hipHostMalloc") &&
+            e->check(hipMemset(c.d_tkeys, 0, cap * 16), "hipMemset") && e->check(hipMemset(c.d_tmeta, 0, cap * 4), "hipMemset");
+  if (!ok) return 1;
+  c.h_slot_keys = new p3::CacheKey[B]();
+  c.out_row.assign(B, -1);
+  c.was_hit.assign(B, 0);
+  c.mask = (unsigned)(cap - 1);
+  c.run = 0;
+  c.on = true;
+  return 0;
+}
+
+int p3hip_cache_stats(const p3hip_engine* e, uint64_t out[4]) {
+  out[0] = e->cache.lookups; out[1] = e->cache.hits; out[2] = e->cache.inserts; out[3] = e->cache.on ? (uint64_t)e->cache.mask + 1 : 0;
+  return e->cache.on ? 0 : 1;
 }
 
 // Compacts every dirty slot (loaded and not yet fetched, slot_state.h) into the dense upload.
@@ -759,6 +838,12 @@ static int gather_loaded(p3hip_engine* e) {
   const bool all = (e->flags & P3HIP_FLAG_RUN_ALL_SLOTS) != 0;
   const int n = e->slots.gather(all, [&](int s, int row) {
     memcpy(e->h_feats_compact + (size_t)row * kFeatBytes, e->h_feats + (size_t)s * kFeatBytes, kFeatBytes);
+    if (e->cache.on) {
+      e->cache.h_keys[row] = e->cache.h_slot_keys[s];
+      e->cache.out_row[row] = row;   // p3hip_run re-maps (misses first, then hits)
+      e->cache.was_hit[row] = 0;
+      e->cache.h_sym[row] = (unsigned)e->cache.h_slot_keys[s].sym;
+    }
   });
   e->last_n = n;
   return n;
@@ -780,10 +865,84 @@ int p3hip_forward_resident(p3hip_engine* e, int n_positions) {
 
 int p3hip_sync(p3hip_engine* e) { return e->bind() && e->check(hipStreamSynchronize(e->stream), "sync") ? 0 : 1; }
 
+// p3hip_run with the cache on: probe, evaluate the misses only, fill the hits from the table, store the misses.
+// d_out / h_out rows: the misses first (in row order), then the hits (in row order); cache.out_row maps.
+static int run_cached(p3hip_engine* e, int n) {
+  auto& c = e->cache;
+  hipStream_t s = e->stream;
+  const size_t B = (size_t)e->batch;
+  ++c.run;
+  if (!e->check(hipMemcpyAsync(e->d_feats, e->h_feats_compact, (size_t)n * kFeatBytes, hipMemcpyHostToDevice, s), "H2D features") ||
+      !e->check(hipMemcpyAsync(c.d_keys, c.h_keys, (size_t)n * sizeof(p3::CacheKey), hipMemcpyHostToDevice, s), "H2D keys")) return 1;
+  p3::CacheArgs a{};
+  a.keys = c.d_keys; a.n = n; a.tkeys = c.d_tkeys; a.tmeta = c.d_tmeta; a.tvals = c.d_tvals; a.mask = c.mask; a.run = c.run;
+  a.hit = c.d_hit; a.victim = c.d_victim; a.out = e->d_out; a.out_sym = c.d_sym;
+  if (!e->check(p3::launch_cache_probe(a, s), "launch k_cache_probe") ||
+      !e->check(hipMemcpyAsync(c.h_hit, c.d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, s), "D2H hits") ||
+      !e->check(hipMemcpyAsync(c.h_victim, c.d_victim, (size_t)n * 4, hipMemcpyDeviceToHost, s), "D2H victims") ||
+      !e->check(hipStreamSynchronize(s), "sync")) return 1;
+  int* miss_rows = c.h_lists;
+  int* hit_idx = c.h_lists + B;
+  int* ins_rows = c.h_lists + 2 * B;
+  int* ins_src = c.h_lists + 3 * B;
+  int* ins_idx = c.h_lists + 4 * B;
+  int nm = 0, nh = 0, ni = 0;
+  for (int r = 0; r < n; ++r) nm += c.h_hit[r] < 0;
+  int mi = 0, hi = 0;
+  // entries this run reads (hits) or has already given to an insert: one writer per entry, no reader evicted
+  std::unordered_set<int> claimed;
+  for (int r = 0; r < n; ++r) if (c.h_hit[r] >= 0) claimed.insert(c.h_hit[r]);
+  for (int r = 0; r < n; ++r) {
+    const bool keyed = (c.h_keys[r].lo | c.h_keys[r].hi) != 0;
+    c.lookups += keyed;
+    if (c.h_hit[r] >= 0) {
+      c.was_hit[r] = 1;
+      c.out_row[r] = nm + hi;
+      hit_idx[hi++] = c.h_hit[r];
+      ++c.hits;
+    } else {
+      c.was_hit[r] = 0;
+      c.out_row[r] = mi;
+      c.h_sym[mi] = (unsigned)c.h_keys[r].sym;
+      miss_rows[mi] = r;
+      const int v = c.h_victim[r];
+      if (keyed && v >= 0 && claimed.insert(v).second) {
+        ins_rows[ni] = r; ins_src[ni] = mi; ins_idx[ni] = v; ++ni;
+      }
+      ++mi;
+    }
+  }
+  nh = hi;
+  if (!e->check(hipMemcpyAsync(c.d_lists, c.h_lists, 5 * B * 4, hipMemcpyHostToDevice, s), "H2D lists")) return 1;
+  if (nm > 0) {
+    a.rows = c.d_lists; a.m = nm; a.feats_in = e->d_feats; a.feats_out = c.d_feats2;
+    if (!e->check(p3::launch_cache_gather(a, s), "launch k_cache_gather")) return 1;
+    unsigned char* keep = e->d_feats;
+    e->d_feats = c.d_feats2;
+    const bool ok = enqueue_forward(e, nm);
+    e->d_feats = keep;
+    if (!ok) return 1;
+  }
+  if (nh > 0) {
+    a.idx = c.d_lists + B; a.m = nh; a.out_row0 = nm;
+    if (!e->check(p3::launch_cache_fill(a, s), "launch k_cache_fill")) return 1;
+  }
+  if (ni > 0) {
+    a.rows = c.d_lists + 2 * B; a.src = c.d_lists + 3 * B; a.idx = c.d_lists + 4 * B; a.m = ni;
+    if (!e->check(p3::launch_cache_insert(a, s), "launch k_cache_insert")) return 1;
+    c.inserts += ni;
+  }
+  if (!e->check(hipMemcpy2DAsync(e->h_out, p3::kResultFloats * 4, e->d_out, p3::kOutStride * 4,
+                                 p3::kResultFloats * 4, n, hipMemcpyDeviceToHost, s), "D2H results")) return 1;
+  if (nh > 0 && !e->check(hipMemcpyAsync(c.h_sym + nm, c.d_sym + nm, (size_t)nh * 4, hipMemcpyDeviceToHost, s), "D2H symmetries")) return 1;
+  return e->check(hipStreamSynchronize(s), "sync") ? 0 : 1;
+}
+
 int p3hip_run(p3hip_engine* e) {
   if (!e->bind()) return 1;
   int n = gather_loaded(e);
   if (n == 0) return 0;
+  if (e->cache.on) return run_cached(e, n);
   if (!e->check(hipMemcpyAsync(e->d_feats, e->h_feats_compact, (size_t)n * kFeatBytes,
                                hipMemcpyHostToDevice, e->stream), "H2D features")) return 1;
   if (!enqueue_forward(e, n)) return 1;
@@ -794,7 +953,7 @@ int p3hip_run(p3hip_engine* e) {
 
 int p3hip_get_slot(p3hip_engine* e, int slot, p3hip_result* out) {
   if (slot < 0 || slot >= e->batch) return 1;
-  int row = e->slots.row(slot);
+  int row = e->out_row_of(slot);
   if (row < 0) return 2;
   const float* r = e->h_out + (size_t)row * p3::kResultFloats;
   memcpy(out->move_logits, r + p3::kOffMoveLogits, 362 * 4);
@@ -807,9 +966,18 @@ int p3hip_get_slot(p3hip_engine* e, int slot, p3hip_result* out) {
   return 0;
 }
 
+int p3hip_get_slot_keyed(p3hip_engine* e, int slot, p3hip_result* out, int* symmetry, int* from_cache) {
+  if (slot < 0 || slot >= e->batch) return 1;
+  const int row = e->slots.row(slot), orow = e->out_row_of(slot);
+  if (row < 0) return 2;
+  if (symmetry) *symmetry = e->cache.on ? (int)e->cache.h_sym[orow] : 0;
+  if (from_cache) *from_cache = e->cache.on ? e->cache.was_hit[row] : 0;
+  return p3hip_get_slot(e, slot, out);
+}
+
 int p3hip_get_ownership(p3hip_engine* e, int slot, float out[P3HIP_NUM_LOCS]) {
   if (slot < 0 || slot >= e->batch) return 1;
-  int row = e->slots.row(slot);
+  int row = e->out_row_of(slot);
   if (row < 0) return 2;
   if (!e->bind()) return 1;
   if (!e->check(hipMemcpy(out, e->d_out + (size_t)row * p3::kOutStride + p3::kOffOwnership,
@@ -820,7 +988,7 @@ int p3hip_get_ownership(p3hip_engine* e, int slot, float out[P3HIP_NUM_LOCS]) {
 
 int p3hip_get_raw(p3hip_engine* e, int slot, float* out) {
   if (slot < 0 || slot >= e->batch) return 1;
-  int row = e->slots.row(slot);
+  int row = e->out_row_of(slot);
   if (row < 0) return 2;
   std::vector<float> rec(p3::kOutStride);
   if (!e->bind()) return 1;

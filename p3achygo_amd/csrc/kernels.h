@@ -150,6 +150,38 @@ hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s);
 // layer-wise conv: (kw, cin, cout) in {(1,384,192), (3,192,192), (1,192,384)}; two positions per workgroup
 hipError_t launch_lconv(int kw, int cin, int cout, const LConvArgs& a, int n_cu, hipStream_t s);
 hipError_t launch_heads(const HeadsArgs& a, int grid, hipStream_t s);
+
+// ---- on-device NN cache (engine.cpp p3hip_cache_*) -------------------------------------------------
+// Open-addressed table in HBM: 128-bit keys, kCacheWays consecutive entries probed per key, one result
+// record (kOutStride floats, the layout k_heads writes) per entry.  meta = symmetry (3 bits) | last-use
+// run counter << 3.  A zero key is "no key": never looked up, never stored.
+constexpr int kCacheWays = 8;
+struct CacheKey { unsigned long long lo, hi, sym; };
+struct CacheArgs {
+  const CacheKey* keys;            // [n] keys of this run's rows
+  int n;
+  unsigned long long* tkeys;       // [cap][2]
+  unsigned* tmeta;                 // [cap]
+  float* tvals;                    // [cap][kOutStride]
+  unsigned mask;                   // cap - 1
+  unsigned run;                    // run counter (for replacement)
+  int* hit;                        // [n] entry index, -1 = miss
+  int* victim;                     // [n] entry a miss may take (-1: none, key 0)
+  // fill / insert / gather lists (device copies of what the host decided after the probe)
+  const int* rows;                 // [m] row of this run (gather: its features; insert: its key)
+  const int* src;                  // [m] insert: row of `out` that holds the result
+  const int* idx;                  // [m] table entry
+  int m;
+  int out_row0;                    // fill: first destination row of d_out
+  float* out;                      // [batch][kOutStride]
+  unsigned* out_sym;               // fill: [n] symmetry of the stored result, by destination row
+  const unsigned char* feats_in;   // gather
+  unsigned char* feats_out;
+};
+hipError_t launch_cache_probe(const CacheArgs& a, hipStream_t s);
+hipError_t launch_cache_gather(const CacheArgs& a, hipStream_t s);
+hipError_t launch_cache_fill(const CacheArgs& a, hipStream_t s);
+hipError_t launch_cache_insert(const CacheArgs& a, hipStream_t s);
 const char* block_kernel_name(int C, int kind, int L);
 
 }  // namespace p3

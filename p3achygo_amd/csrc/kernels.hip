@@ -1259,6 +1259,93 @@ hipError_t launch_heads(const HeadsArgs& a, int grid, hipStream_t s) {
   return hipErrorInvalidValue;
 }
 
+// =======================================================================================
+// On-device NN cache (the reference caches NNInferResults per thread on the
+// host, cc/nn/nn_interface.cc:107-132, cc/core/lru_cache.h).  Plain HBM byte work: a probe of
+// kCacheWays consecutive entries per key, record copies of kOutStride floats.
+// =======================================================================================
+__global__ void __launch_bounds__(256) k_cache_probe(CacheArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.n) return;
+  const unsigned long long lo = a.keys[r].lo, hi = a.keys[r].hi;
+  int hit = -1, victim = -1;
+  if (lo | hi) {
+    unsigned best_age = 0;
+    bool have = false;
+    const unsigned h = (unsigned)(lo ^ (lo >> 32));
+#pragma unroll 1
+    for (int w = 0; w < kCacheWays; ++w) {
+      const unsigned i = (h + (unsigned)w) & a.mask;
+      const unsigned long long tl = a.tkeys[2 * (size_t)i], th = a.tkeys[2 * (size_t)i + 1];
+      if (tl == lo && th == hi) { hit = (int)i; break; }
+      // replacement: an empty entry first, else the least recently used of the window
+      const unsigned age = (tl | th) ? (a.run - (a.tmeta[i] >> 3)) & 0x1fffffffu : 0xffffffffu;
+      if (!have || age > best_age) { have = true; best_age = age; victim = (int)i; }
+    }
+    if (hit >= 0) victim = -1;
+  }
+  a.hit[r] = hit;
+  a.victim[r] = victim;
+}
+
+// feats_out[j] = feats_in[rows[j]] (1,860 bytes = 465 dwords per position)
+__global__ void __launch_bounds__(256) k_cache_gather(CacheArgs a) {
+  const int j = blockIdx.x;
+  const unsigned* src = (const unsigned*)(a.feats_in + (size_t)a.rows[j] * FeatOff::size);
+  unsigned* dst = (unsigned*)(a.feats_out + (size_t)j * FeatOff::size);
+  for (int i = threadIdx.x; i < FeatOff::size / 4; i += 256) dst[i] = src[i];
+}
+
+// out[out_row0 + j] = tvals[idx[j]]; the entry is marked used in this run
+__global__ void __launch_bounds__(256) k_cache_fill(CacheArgs a) {
+  const int j = blockIdx.x;
+  const int e = a.idx[j];
+  const f32x4* src = (const f32x4*)(a.tvals + (size_t)e * kOutStride);
+  f32x4* dst = (f32x4*)(a.out + (size_t)(a.out_row0 + j) * kOutStride);
+  static_assert(kOutStride % 4 == 0, "records are copied in 16-byte pieces");
+  for (int i = threadIdx.x; i < kOutStride / 4; i += 256) dst[i] = src[i];
+  if (threadIdx.x == 0) {
+    const unsigned meta = a.tmeta[e];
+    a.out_sym[a.out_row0 + j] = meta & 7u;
+    a.tmeta[e] = (meta & 7u) | (a.run << 3);
+  }
+}
+
+// tvals[idx[j]] = out[rows[j]], key and symmetry of row rows[j]; the host lists every entry at most once
+__global__ void __launch_bounds__(256) k_cache_insert(CacheArgs a) {
+  const int j = blockIdx.x;
+  const int e = a.idx[j], r = a.rows[j];
+  const f32x4* src = (const f32x4*)(a.out + (size_t)a.src[j] * kOutStride);
+  f32x4* dst = (f32x4*)(a.tvals + (size_t)e * kOutStride);
+  for (int i = threadIdx.x; i < kOutStride / 4; i += 256) dst[i] = src[i];
+  if (threadIdx.x == 0) {
+    a.tkeys[2 * (size_t)e] = a.keys[r].lo;
+    a.tkeys[2 * (size_t)e + 1] = a.keys[r].hi;
+    a.tmeta[e] = ((unsigned)a.keys[r].sym & 7u) | (a.run << 3);
+  }
+}
+
+hipError_t launch_cache_probe(const CacheArgs& a, hipStream_t s) {
+  if (a.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cache_probe, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_cache_gather(const CacheArgs& a, hipStream_t s) {
+  if (a.m <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cache_gather, dim3(a.m), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_cache_fill(const CacheArgs& a, hipStream_t s) {
+  if (a.m <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cache_fill, dim3(a.m), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_cache_insert(const CacheArgs& a, hipStream_t s) {
+  if (a.m <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cache_insert, dim3(a.m), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 const char* block_kernel_name(int C, int kind, int L) {
   (void)L;
   if (kind == 0) return C == 256 ? "k_block<256,128,btl>" : "k_block<128,64,btl>";

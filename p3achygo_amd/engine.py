@@ -28,6 +28,7 @@ EXPORTS = [
     "p3hip_batch_size", "p3hip_load_slot", "p3hip_run", "p3hip_get_slot", "p3hip_get_ownership",
     "p3hip_last_error", "p3hip_forward_resident", "p3hip_upload", "p3hip_sync", "p3hip_get_raw",
     "p3hip_time_trunk_kernel", "p3hip_flops_per_position",
+    "p3hip_cache_enable", "p3hip_load_slot_keyed", "p3hip_get_slot_keyed", "p3hip_cache_stats",
 ]
 
 FLAG_RUN_ALL_SLOTS = 2
@@ -77,6 +78,10 @@ def lib():
         L.p3hip_upload.argtypes = [C.c_void_p]
         L.p3hip_sync.argtypes = [C.c_void_p]
         L.p3hip_get_raw.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.p3hip_cache_enable.argtypes = [C.c_void_p, C.c_int]
+        L.p3hip_load_slot_keyed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+        L.p3hip_get_slot_keyed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.p3hip_cache_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.p3hip_time_trunk_kernel.restype = C.c_double
         L.p3hip_time_trunk_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double),
                                               C.POINTER(C.c_char_p)]
@@ -148,6 +153,26 @@ class HipEngine:
         own = np.zeros(361, np.float32)
         self._ck(self._L.p3hip_get_ownership(self._h, batch_id, own.ctypes.data), "GetOwnership")
         return own
+
+    # -- on-device NN cache (include/p3hip.h) ---------------------------------------------
+    def EnableCache(self, log2_entries: int) -> None:
+        self._ck(self._L.p3hip_cache_enable(self._h, log2_entries), "EnableCache")
+
+    def LoadBatchKeyed(self, batch_id: int, features, key_lo: int, key_hi: int, symmetry: int = 0) -> None:
+        ptr = features.ctypes.data if isinstance(features, np.ndarray) else C.addressof(features)
+        self._ck(self._L.p3hip_load_slot_keyed(self._h, batch_id, ptr, key_lo, key_hi, symmetry), "LoadBatchKeyed")
+
+    def GetBatchKeyed(self, batch_id: int, result: Result = None):
+        """(result, symmetry of the returned result, came from the table)"""
+        result = result if result is not None else Result()
+        sym, hit = C.c_int(0), C.c_int(0)
+        self._ck(self._L.p3hip_get_slot_keyed(self._h, batch_id, C.addressof(result), C.byref(sym), C.byref(hit)), "GetBatchKeyed")
+        return result, sym.value, bool(hit.value)
+
+    def cache_stats(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        self._L.p3hip_cache_stats(self._h, out)
+        return {"lookups": out[0], "hits": out[1], "stored": out[2], "entries": out[3]}
 
     # -- measurement / test hooks -------------------------------------------------------
     def load_all(self, feats_rec: np.ndarray) -> None:

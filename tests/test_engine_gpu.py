@@ -463,3 +463,88 @@ def test_repeated_and_concurrent_runs_are_bit_identical(built, weight_files):
     ths = [threading.Thread(target=worker, args=(outs, 20)) for _ in range(2)]
     [t.start() for t in ths]; [t.join() for t in ths]
     assert len(outs) == 2 and outs[0] == outs[1] == solo[0]
+
+
+@pytest.mark.gpu
+def test_device_nn_cache_serves_hits_bit_identical_and_evaluates_only_misses(built, weight_files):
+    """On-device NN cache (p3hip_cache_*; the reference's per-thread LRU of cc/nn/nn_interface.cc:107-132 moved into
+    HBM).  A keyed position is evaluated once; later runs return the stored record bit for bit, with the symmetry
+    it was stored under, from whatever slot asks; unkeyed slots are never cached; runs that mix hits, misses,
+    duplicate new keys and unkeyed slots equal an engine without the cache; a table far smaller than the key set
+    (forced evictions) never returns another key's record."""
+    from p3achygo_amd import engine, features
+    name = "test_b3c128btl2"
+    path = weight_files(name, randomize=True)
+    pos = features.random_positions(96, seed=77, n_games=24)
+    ref = engine.HipEngine(path, 96)
+    ref.load_all(pos)
+    ref.RunInference()
+    want = np.stack([ref.get_raw(i) for i in range(96)])
+    ref.close()
+    key = lambda i: (0x9E3779B97F4A7C15 * (i + 1) & (2**64 - 1), 0xC2B2AE3D27D4EB4F * (i + 7) & (2**64 - 1))
+
+    eng = engine.HipEngine(path, 64)
+    eng.EnableCache(10)
+    # run 1: 48 keyed positions (symmetry = i % 8 recorded with each) + 16 unkeyed: everything is evaluated
+    for s in range(48):
+        eng.LoadBatchKeyed(s, pos[s:s + 1], *key(s), symmetry=s % 8)
+    for s in range(48, 64):
+        eng.LoadBatch(s, pos[s:s + 1])
+    eng.RunInference()
+    for s in range(64):
+        raw = eng.get_raw(s)
+        _, sym, hit = eng.GetBatchKeyed(s)
+        assert np.array_equal(raw, want[s]) and not hit and sym == (s % 8 if s < 48 else 0)
+    assert eng.cache_stats() == {"lookups": 48, "hits": 0, "stored": 48, "entries": 1024}
+    # run 2: the same keys from other slots (features deliberately those of ANOTHER position: a hit never looks at
+    # them), 8 new keys of which two are the same key twice, 8 unkeyed
+    for s in range(48):
+        k = 47 - s
+        eng.LoadBatchKeyed(s, pos[(k + 1) % 96:(k + 1) % 96 + 1], *key(k), symmetry=7)
+    for s in range(48, 56):
+        p = 64 + min(s - 48, 6)            # slots 54 and 55 both carry position / key 70
+        eng.LoadBatchKeyed(s, pos[p:p + 1], *key(p), symmetry=3)
+    for s in range(56, 64):
+        eng.LoadBatch(s, pos[s:s + 1])
+    eng.RunInference()
+    for s in range(48):
+        k = 47 - s
+        raw = eng.get_raw(s)
+        res, sym, hit = eng.GetBatchKeyed(s)
+        assert hit and sym == k % 8 and np.array_equal(raw, want[k])
+        assert np.array_equal(np.ctypeslib.as_array(res.move_logits), want[k][:362])
+    for s in range(48, 56):
+        p = 64 + min(s - 48, 6)
+        _, sym, hit = eng.GetBatchKeyed(s)
+        assert not hit and sym == 3 and np.array_equal(eng.get_raw(s), want[p])
+    for s in range(56, 64):
+        assert np.array_equal(eng.get_raw(s), want[s])
+        eng.GetBatch(s)
+    st = eng.cache_stats()
+    assert st["lookups"] == 48 + 56 and st["hits"] == 48 and st["stored"] == 48 + 7
+    # run 3: a partial run (ragged: 5 slots), all hits including the duplicated key
+    for s, p in enumerate([70, 64, 3, 69, 40]):
+        eng.LoadBatchKeyed(s, pos[0:1], *key(p), symmetry=0)
+    eng.RunInference()
+    for s, p in enumerate([70, 64, 3, 69, 40]):
+        _, sym, hit = eng.GetBatchKeyed(s)
+        assert hit and sym == (3 if p >= 64 else p % 8) and np.array_equal(eng.get_raw(s), want[p])
+    eng.close()
+
+    # 16 entries for 96 keys: whatever is evicted is simply evaluated again; a record is never served for the wrong key
+    small = engine.HipEngine(path, 32)
+    small.EnableCache(4)
+    rng = np.random.default_rng(5)
+    hits = 0
+    for it in range(12):
+        ids = rng.choice(96, 32, replace=False)
+        for s, p in enumerate(ids):
+            small.LoadBatchKeyed(s, pos[p:p + 1], *key(int(p)), symmetry=int(p) % 8)
+        small.RunInference()
+        for s, p in enumerate(ids):
+            raw = small.get_raw(s)
+            _, sym, hit = small.GetBatchKeyed(s)
+            hits += hit
+            assert sym == int(p) % 8 and np.array_equal(raw, want[p])
+    assert 0 < hits < 12 * 32 and small.cache_stats()["hits"] == hits
+    small.close()

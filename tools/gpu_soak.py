@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from p3achygo_amd import host_api, netspec
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60
-cfg = netspec.CONFIGS["b12c256btl3"]
+cfg = netspec.CONFIGS[sys.argv[3] if len(sys.argv) > 3 else "b12c256btl3"]
 d = tempfile.mkdtemp()
 path = os.path.join(d, "n.p3w")
 netspec.save_p3w(path, cfg, netspec.generate_weights(cfg))

@@ -21,6 +21,15 @@ struct Evaluator {
   virtual bool Run() = 0;
   virtual void Get(int slot, p3hip_result& r) = 0;
   virtual void GetOwnership(int slot, float out[P3HIP_NUM_LOCS]) { std::memset(out, 0, sizeof(float) * P3HIP_NUM_LOCS); }
+  // On-device NN cache (include/p3hip.h p3hip_cache_*): an engine without one says no and the host keeps its own.
+  // LoadKeyed carries the position's 128-bit key and the symmetry of the features; GetKeyed returns the symmetry
+  // of the result that comes back (the stored one on a hit) for the caller to undo.
+  virtual bool EnableDeviceCache(int /*log2_entries*/) { return false; }
+  virtual void LoadKeyed(int slot, const p3hip_features& f, uint64_t /*key_lo*/, uint64_t /*key_hi*/, int /*symmetry*/) { Load(slot, f); }
+  virtual void GetKeyed(int slot, p3hip_result& r, int* /*symmetry: left as given*/, bool* from_cache) {
+    Get(slot, r);
+    if (from_cache) *from_cache = false;
+  }
 };
 
 // Uniform policy, even outcome, zero score: the reference's NullEngine
@@ -53,6 +62,10 @@ struct HipEvaluator final : Evaluator {
   decltype(&p3hip_get_ownership) get_own = nullptr;
   decltype(&p3hip_last_error) last_error = nullptr;
   decltype(&p3hip_create_error) create_error = nullptr;
+  decltype(&p3hip_cache_enable) cache_enable = nullptr;
+  decltype(&p3hip_load_slot_keyed) load_keyed = nullptr;
+  decltype(&p3hip_get_slot_keyed) get_keyed = nullptr;
+  decltype(&p3hip_cache_stats) cache_stats = nullptr;
   std::string err;
 
   bool Open(const char* lib_path, const char* weights, int batch, int device) {
@@ -66,6 +79,10 @@ struct HipEvaluator final : Evaluator {
     get_own = (decltype(get_own))dlsym(lib, "p3hip_get_ownership");
     last_error = (decltype(last_error))dlsym(lib, "p3hip_last_error");
     create_error = (decltype(create_error))dlsym(lib, "p3hip_create_error");
+    cache_enable = (decltype(cache_enable))dlsym(lib, "p3hip_cache_enable");
+    load_keyed = (decltype(load_keyed))dlsym(lib, "p3hip_load_slot_keyed");
+    get_keyed = (decltype(get_keyed))dlsym(lib, "p3hip_get_slot_keyed");
+    cache_stats = (decltype(cache_stats))dlsym(lib, "p3hip_cache_stats");
     if (!create || !destroy || !load || !run || !get) { err = "missing p3hip symbols"; return false; }
     eng = create(weights, batch, 1, device, 0);
     if (!eng) { err = create_error ? create_error() : "p3hip_create failed"; return false; }
@@ -92,6 +109,20 @@ struct HipEvaluator final : Evaluator {
   }
   void Get(int slot, p3hip_result& r) override {
     if (int rc = get(eng, slot, &r)) Fatal("get_slot", slot, rc);
+  }
+  bool EnableDeviceCache(int log2_entries) override {
+    if (!cache_enable || !load_keyed || !get_keyed) return false;
+    if (cache_enable(eng, log2_entries) != 0) { err = last_error(eng); return false; }
+    return true;
+  }
+  void LoadKeyed(int slot, const p3hip_features& f, uint64_t lo, uint64_t hi, int symmetry) override {
+    if (int rc = load_keyed(eng, slot, &f, lo, hi, symmetry)) Fatal("load_slot_keyed", slot, rc);
+  }
+  void GetKeyed(int slot, p3hip_result& r, int* symmetry, bool* from_cache) override {
+    int sym = 0, hit = 0;
+    if (int rc = get_keyed(eng, slot, &r, &sym, &hit)) Fatal("get_slot_keyed", slot, rc);
+    if (symmetry) *symmetry = sym;
+    if (from_cache) *from_cache = hit != 0;
   }
   void GetOwnership(int slot, float out[P3HIP_NUM_LOCS]) override {
     if (!get_own) Fatal("get_ownership (symbol missing)", slot, -1);

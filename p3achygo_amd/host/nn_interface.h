@@ -137,8 +137,25 @@ class NNInterface final {
   void SetNumCacheLastMoves(int n) { num_cache_last_moves_ = n; }   // [0, 5], default 5
   Evaluator* engine() { return engine_.get(); }
 
+  // The cache moves from this object's per-thread LRUs into the engine's HBM table (p3hip_cache_*): one table
+  // for every worker and game, looked up and filled by the run itself.  Same contract towards the search — a
+  // position seen before returns the result stored then, un-rotated — except that a hit still takes part in a
+  // run (it costs a table probe, not a forward pass).  False when the engine has no such table.
+  bool EnableDeviceCache(int log2_entries) {
+    device_cache_ = engine_->EnableDeviceCache(log2_entries);
+    return device_cache_;
+  }
+  bool device_cache() const { return device_cache_; }
+  long device_cache_hits() const { return device_hits_.load(std::memory_order_relaxed); }
+
   // Blocks until the result is ready (nn_interface.cc:108-133).
   p3hip_result LoadAndGetInference(int thread_id, const Game& game, Color color_to_move, Probability& prob) {
+    if (device_cache_) {
+      const Symmetry sym = RandomSymmetry(prob.prng());
+      LoadBatchKeyed(thread_id, game, color_to_move, sym);
+      SignalLoadedAndBlockUntilReady(thread_id);
+      return GetBatchKeyed(thread_id, sym);
+    }
     const Key key = MakeKey(game, color_to_move);
     if (caches_[thread_id].Contains(key)) {
       MarkCached(thread_id, true);
@@ -189,6 +206,20 @@ class NNInterface final {
   // async API (nn_interface.cc:172-230)
   void LoadEntry(int thread_id, int offset, const Game& game, Color color_to_move, Probability& prob) {
     const int tid = thread_id + offset;
+    if (device_cache_) {
+      const Symmetry sym = RandomSymmetry(prob.prng());
+      syms_[tid] = sym;
+      LoadBatchKeyed(tid, game, color_to_move, sym);
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        ThreadInfo& t = info_[tid];
+        t.loaded = true;
+        t.res_ready.store(false, std::memory_order_relaxed);
+        t.res_cached = false;
+      }
+      infer_cv_.notify_all();
+      return;
+    }
     const Key key = MakeKey(game, color_to_move);
     if (caches_[tid].Contains(key)) {
       MarkCached(tid, true);
@@ -208,6 +239,10 @@ class NNInterface final {
   }
   p3hip_result FetchEntry(int thread_id, int offset, const Game& game, Color color_to_move) {
     const int tid = thread_id + offset;
+    if (device_cache_) {
+      Wait(tid);
+      return GetBatchKeyed(tid, syms_[tid]);
+    }
     const Key key = MakeKey(game, color_to_move);
     if (caches_[tid].Contains(key)) {
       MarkCached(tid, false);
@@ -289,6 +324,41 @@ class NNInterface final {
     p3hip_features f;
     FillFeatures(game, color_to_move, sym, &f);
     engine_->Load(tid, f);
+  }
+  // 128-bit digest of the NNKey for the engine's table (two independent mixes of the same fields)
+  static void KeyDigest(const Key& k, uint64_t* lo, uint64_t* hi) {
+    uint32_t kb;
+    std::memcpy(&kb, &k.komi, 4);
+    uint64_t a = k.board_hash ^ (uint64_t(uint8_t(k.color)) * 0x9e3779b97f4a7c15ull);
+    uint64_t b = (k.board_hash * 0xd6e8feb86659fd93ull) ^ (uint64_t(kb) << 8) ^ uint64_t(uint8_t(k.color));
+    for (const Loc& l : k.last_moves) {
+      const uint64_t m = uint64_t(uint32_t(l.i * 32 + l.j + 64));
+      a = (a ^ m) * 0xff51afd7ed558ccdull;
+      b = ((b << 7) | (b >> 57)) ^ (m * 0xc2b2ae3d27d4eb4full);
+    }
+    a = (a ^ kb) * 0xc4ceb9fe1a85ec53ull;
+    b = (b ^ (b >> 31)) * 0x94d049bb133111ebull;
+    *lo = a ^ (a >> 29);
+    *hi = b ^ (b >> 32);
+    if ((*lo | *hi) == 0) *lo = 1;   // 0/0 means "no key" to the engine
+  }
+  void LoadBatchKeyed(int tid, const Game& game, Color color_to_move, Symmetry sym) {
+    p3hip_features f;
+    FillFeatures(game, color_to_move, sym, &f);
+    uint64_t lo, hi;
+    KeyDigest(MakeKey(game, color_to_move), &lo, &hi);
+    engine_->LoadKeyed(tid, f, lo, hi, (int)sym);
+  }
+  p3hip_result GetBatchKeyed(int tid, Symmetry loaded_sym) {
+    p3hip_result r;
+    int sym = (int)loaded_sym;
+    bool hit = false;
+    engine_->GetKeyed(tid, r, &sym, &hit);
+    if (hit) device_hits_.fetch_add(1, std::memory_order_relaxed);
+    info_[tid].res_ready.store(false, std::memory_order_release);
+    NotifyInfer();
+    UnapplySymmetry((Symmetry)sym, &r);
+    return r;
   }
   p3hip_result GetBatch(int tid, Symmetry sym) {   // nn_interface.h:254-292
     p3hip_result r;
@@ -413,6 +483,8 @@ class NNInterface final {
   std::vector<LruCache<Key, p3hip_result, KeyHash>> caches_;
   std::thread infer_thread_;
   int num_cache_last_moves_ = 5;
+  bool device_cache_ = false;
+  std::atomic<long> device_hits_{0};
   const SignalKind signal_kind_;
   const int num_shared_tasks_;
   int num_signaled_tasks_ = 0, num_exited_tasks_ = 0;

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <random>
 #include <thread>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -144,7 +145,112 @@ void StressWorker(int tid, NNInterface* black_nn, NNInterface* white_nn, std::at
   }
 }
 
+// ---- an evaluator with the HIP engine's cache rules (include/p3hip.h p3hip_cache_*) -----------------
+// "Evaluates" a position by copying the stones of the (rotated) features into move_logits — so a result,
+// un-rotated by the symmetry it was computed under, must read as the stones of the game itself — and keeps
+// a table of (key -> result, symmetry): a keyed load whose key is in the table is served from it.
+struct KeyedTableEvaluator final : Evaluator {
+  explicit KeyedTableEvaluator(int n) : feats_(n), keys_(n), out_(n), out_sym_(n), out_hit_(n), loaded_(n, 0) {}
+  bool EnableDeviceCache(int) override { return true; }
+  void Load(int t, const p3hip_features& f) override { LoadKeyed(t, f, 0, 0, 0); }
+  void LoadKeyed(int t, const p3hip_features& f, uint64_t lo, uint64_t hi, int sym) override {
+    feats_[t] = f;
+    keys_[t] = {lo, hi, sym};
+    loaded_[t] = 1;
+  }
+  bool Run() override {
+    for (size_t t = 0; t < feats_.size(); ++t) {
+      if (!loaded_[t]) continue;
+      loaded_[t] = 0;
+      const K& k = keys_[t];
+      const bool keyed = (k.lo | k.hi) != 0;
+      ++lookups_;
+      auto it = keyed ? table_.find({k.lo, k.hi}) : table_.end();
+      if (it != table_.end()) {
+        out_[t] = it->second.first;
+        out_sym_[t] = it->second.second;
+        out_hit_[t] = true;
+        ++hits_;
+        continue;
+      }
+      p3hip_result r;
+      std::memset(&r, 0, sizeof r);
+      for (int i = 0; i < kNumLocs; ++i) r.move_logits[i] = r.move_probs[i] = r.opt_move_probs[i] = (float)feats_[t].board[i];
+      r.value_probs[1] = 1.0f;
+      out_[t] = r;
+      out_sym_[t] = k.sym;
+      out_hit_[t] = false;
+      ++evaluated_;
+      if (keyed) table_[{k.lo, k.hi}] = {r, k.sym};
+    }
+    return true;
+  }
+  void Get(int t, p3hip_result& r) override { r = out_[t]; }
+  void GetKeyed(int t, p3hip_result& r, int* sym, bool* hit) override {
+    r = out_[t];
+    if (sym) *sym = out_sym_[t];
+    if (hit) *hit = out_hit_[t];
+  }
+  struct K { uint64_t lo, hi; int sym; };
+  struct PH { size_t operator()(const std::pair<uint64_t, uint64_t>& p) const { return (size_t)(p.first ^ (p.second * 0x9e3779b97f4a7c15ull)); } };
+  std::vector<p3hip_features> feats_;
+  std::vector<K> keys_;
+  std::vector<p3hip_result> out_;
+  std::vector<int> out_sym_;
+  std::vector<char> out_hit_, loaded_;
+  std::unordered_map<std::pair<uint64_t, uint64_t>, std::pair<p3hip_result, int>, PH> table_;
+  long lookups_ = 0, hits_ = 0, evaluated_ = 0;
+};
+
 }  // namespace
+
+extern "C" {
+// NNInterface over an engine-side cache (EnableDeviceCache): `rounds` passes over `positions` random-playout
+// positions through LoadAndGetInference (a fresh random symmetry per call) and, every other round, through the
+// async LoadEntry / FetchEntry pair.  Every result, un-rotated by the interface, must show the game's own
+// stones.  out: {mismatching results, engine evaluations, engine hits, interface-counted hits, distinct keys}.
+int p3host_test_nn_device_cache(int positions, int rounds, uint64_t seed, long out[5]) {
+  auto* ev = new KeyedTableEvaluator(4);
+  NNInterface nn(1, NNInterface::kTimeoutUs, 1 << 10, std::unique_ptr<Evaluator>(ev));
+  if (!nn.EnableDeviceCache(10) || !nn.device_cache()) return 1;
+  Probability prob(seed);
+  std::vector<Game> games;
+  std::vector<Color> to_move;
+  for (int g = 0; g < positions; ++g) {
+    Game game(7.5f, true);
+    Color c = kBlack;
+    const int plies = 5 + (int)(RandRange(prob.prng(), 0, 60));
+    for (int m = 0; m < plies && !game.IsGameOver(); ++m) {
+      Loc mv = kPassLoc;
+      for (int tries = 0; tries < 40; ++tries) {
+        const int idx = RandRange(prob.prng(), 0, kNumLocs);
+        if (game.IsValidMove(AsLoc(idx), c)) { mv = AsLoc(idx); break; }
+      }
+      game.PlayMove(mv, c);
+      c = Opp(c);
+    }
+    games.push_back(game);
+    to_move.push_back(c);
+  }
+  long bad = 0;
+  auto check = [&](const Game& game, const p3hip_result& r) {
+    for (int i = 0; i < kNumLocs; ++i)
+      if (r.move_logits[i] != (float)game.board().at(i) || r.move_probs[i] != r.move_logits[i] || r.opt_move_probs[i] != r.move_logits[i]) { ++bad; return; }
+  };
+  for (int round = 0; round < rounds; ++round)
+    for (int g = 0; g < positions; ++g) {
+      if (round % 2 == 0) {
+        check(games[g], nn.LoadAndGetInference(0, games[g], to_move[g], prob));
+      } else {
+        nn.LoadEntry(0, 0, games[g], to_move[g], prob);
+        nn.SignalReadyForInference();
+        check(games[g], nn.FetchEntry(0, 0, games[g], to_move[g]));
+      }
+    }
+  out[0] = bad; out[1] = ev->evaluated_; out[2] = ev->hits_; out[3] = nn.device_cache_hits(); out[4] = (long)ev->table_.size();
+  return 0;
+}
+}
 
 extern "C" {
 

@@ -1125,6 +1125,13 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
 // num_shared_search_tasks = num_games, batch = num_games * threads_per_game slots and the
 // per-thread NN cache on (cache_size entries in total per interface), the side to move running
 // the threaded mcts::Search (threaded_search.h) on slot range [game * T, (game + 1) * T).
+// Thread-per-game drivers: keep the NN cache in the engine's HBM table (p3hip_cache_*, 2^log2_entries entries per
+// engine) instead of NNInterface's per-thread host LRUs; 0 = host caches (the reference's arrangement).
+static std::atomic<int> g_device_nn_cache_log2{0};
+static std::atomic<long> g_device_nn_cache_hits{0};
+void p3host_set_device_nn_cache(int log2_entries) { g_device_nn_cache_log2.store(log2_entries < 0 ? 0 : log2_entries); }
+long p3host_device_nn_cache_hits() { return g_device_nn_cache_hits.load(); }   // of the last thread-per-game match
+
 int p3host_eval_match_threads(const char* engine_lib, const char* cur_weights, const char* cand_weights, int device,
                               int num_games, int visits_per_move, int threads_per_game, int max_moves,
                               long cache_size, uint64_t seed, p3host_eval_stats* out, char* err) {
@@ -1147,6 +1154,11 @@ int p3host_eval_match_threads(const char* engine_lib, const char* cur_weights, c
     }
     nn[e].reset(new NNInterface(batch, NNInterface::kTimeoutUs, (size_t)cache_size, std::move(ev),
                                 NNInterface::SignalKind::kExplicit, num_games));
+    const int dc = g_device_nn_cache_log2.load();
+    if (dc > 0 && !use_null && !nn[e]->EnableDeviceCache(dc)) {
+      if (err) snprintf(err, 256, "the engine has no on-device NN cache (p3hip_cache_enable)");
+      return 1;
+    }
   }
   std::vector<EvalGameOutcome> outcomes(num_games);
   std::vector<long> moves(num_games, 0), visits(num_games, 0), collisions(num_games, 0);
@@ -1213,6 +1225,7 @@ int p3host_eval_match_threads(const char* engine_lib, const char* cur_weights, c
       moves[g] = game.num_moves();
     });
   for (auto& t : threads) t.join();
+  g_device_nn_cache_hits.store(nn[0]->device_cache_hits() + nn[1]->device_cache_hits());
   if (out) {
     std::memset(out, 0, sizeof *out);
     FinishEvalMatch(outcomes, out);

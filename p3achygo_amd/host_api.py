@@ -330,6 +330,17 @@ def eval_match(cur_weights: str | None, cand_weights: str | None, num_games: int
     return st
 
 
+def set_device_nn_cache(log2_entries: int) -> None:
+    """Thread-per-game drivers: NN cache in the engine's HBM table (2^log2_entries entries per engine); 0 = host LRUs."""
+    lib().p3host_set_device_nn_cache(int(log2_entries))
+
+
+def device_nn_cache_hits() -> int:
+    L = lib()
+    L.p3host_device_nn_cache_hits.restype = C.c_long
+    return int(L.p3host_device_nn_cache_hits())
+
+
 def eval_match_threads(cur_weights: str | None, cand_weights: str | None, num_games: int, visits_per_move: int = 128,
                        threads_per_game: int = 8, max_moves: int = 600, cache_size: int = 1 << 20, seed: int = 1,
                        device: int = 0, engine_lib: str | None = None) -> EvalStats:

@@ -390,6 +390,23 @@ def test_eval_match_on_hip_engines(built, weight_files):
 
 
 @pytest.mark.gpu
+def test_thread_per_game_match_with_the_nn_cache_in_hbm(built, weight_files):
+    """The reference's shape of an evaluation match (one thread per game, two NNInterfaces, threaded search) with
+    the NN cache in each engine's HBM table instead of the interfaces' host LRUs (host_api.set_device_nn_cache):
+    the match completes, every game has a result, and positions met again (both players search the same game,
+    transpositions inside a search) are served from the tables."""
+    from p3achygo_amd import host_api
+    host_api.set_device_nn_cache(14)
+    try:
+        st = host_api.eval_match_threads(weight_files("test_b3c128btl2"), weight_files("test_b3c128nbt"), num_games=6,
+                                         visits_per_move=24, threads_per_game=4, max_moves=16, cache_size=0, seed=5)
+    finally:
+        host_api.set_device_nn_cache(0)
+    assert st.games == 6 and st.cur_wins + st.cand_wins + st.draws == 6 and st.moves > 6
+    assert host_api.device_nn_cache_hits() > 0
+
+
+@pytest.mark.gpu
 def test_edge_cases_empty_single_and_flags(built, weight_files):
     """Empty run (no slot loaded) is a no-op, a batch of one works, RUN_ALL_SLOTS evaluates the
     static batch like the TRT engine (trt_engine.cc:238-304), unsupported architectures and

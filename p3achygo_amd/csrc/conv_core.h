@@ -563,7 +563,7 @@ struct XRegs { h8 v[kXLoads]; };
 template <class G>
 __device__ __forceinline__ void stage_load(XRegs<G>& xr, const _Float16* __restrict__ x, int C,
                                            int pos0, int npos, int cblk0) {
-  static_assert(G::NPOS * G::NCH == 16 && kXLoads * 32 >= kNLoc, "staging map");
+  static_assert(G::NPOS * G::NCH * 32 == G::NW * 64 && kXLoads * 32 >= kNLoc, "staging map: one (position, chunk) per 32 threads");
   const int tid = launder(threadIdx.x);
   const int combo = tid >> 5, l32 = tid & 31;
   const int p = combo / G::NCH, kc = combo - p * G::NCH;

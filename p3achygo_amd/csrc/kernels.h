@@ -106,6 +106,7 @@ struct LConvArgs {
   int pre, act, res, dual;
   const float *scale_in, *shift_in;    // folded BN of the prologue   [CIN]
   const float *scale_out, *shift_out;  // folded BN of the epilogue   [COUT]
+  int pair_split;   // 4-wave form: blocks >= pair_split are the second workgroup of their CU (0: no priority turns)
 };
 
 struct BDenseArgs {

@@ -550,11 +550,16 @@ __global__ void __launch_bounds__(kWG, 2) k_conv1x1(Conv1x1Args a) {
 //                                        so inner layers stage without VALU work)
 //   res : out += acc                    (residual, in place)
 // =======================================================================================
-template <int KW, int CIN, int COUT, bool PRE, bool ACT, bool RES, bool DUAL = false>
-__global__ void __launch_bounds__(kWG, 2) k_lconv(LConvArgs a) {
+// NW = 4 (the shipped form; NW = 8 = two positions per 512-thread workgroup, one per CU, P3HIP_LCONV_WG8): a
+// 256-thread workgroup per position — 1x1: 52 KB of activations + 24 KB of ring, 3x3: 60.6 KB + 12 KB (K = 32 ring
+// steps) — so that TWO workgroups share a CU and one's loads, stores and BN + mish run under the other's K loop;
+// they take turns at the higher wave priority, one position group each (see BlockArgs::pair_turns).
+template <int KW, int CIN, int COUT, bool PRE, bool ACT, bool RES, bool DUAL = false, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, 2) k_lconv(LConvArgs a) {
   static_assert(!(ACT && DUAL), "act stores the activated tensor only, dual stores both");
-  constexpr int CB = 64, NPOS = 2, CP = 64;
-  using G = Geo<NPOS, CB, KW>;
+  constexpr int CB = 64, NPOS = NW == 8 ? 2 : 1, CP = 64;
+  // 3x3 layers in the 4-wave form: K = 32 ring steps (60.6 KB of activations + 12 KB of ring), as in k_block
+  using G = Geo<NPOS, CB, KW, NW, (NW == 4 && KW == 3) ? 2 : kKMS>;
   using T = Tiling<G, CP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   act_zero<G>(smem);
@@ -563,13 +568,18 @@ __global__ void __launch_bounds__(kWG, 2) k_lconv(LConvArgs a) {
   const int cp = (blockIdx.x >> 3) % NCP;
   const int pg0 = (blockIdx.x / (8 * NCP)) * 8 + (blockIdx.x & 7);
   const int pg_stride = gridDim.x / NCP;
-  Ring<T::RS> ring;
+  Ring<T::RS, G::NW, G::RD> ring;
   ring_init(ring, smem, (const char*)a.wstream + (size_t)cp * (a.nms_total / NCP) * T::RS, a.nms_total / NCP, G::ACT_BYTES);
   lds_barrier();
   XRegs<G> xr;   // software-pipelined staging, as in k_conv1x1
   stage_load<G>(xr, a.in, CIN, pg0 * NPOS, a.npos, 0);
   int pending_stores = 0;
-  for (int pos0 = pg0 * NPOS; pos0 < a.npos; pos0 += pg_stride * NPOS) {
+  int turn = 0;
+  for (int pos0 = pg0 * NPOS; pos0 < a.npos; pos0 += pg_stride * NPOS, ++turn) {
+    if (NW == 4 && a.pair_split > 0) {
+      if (((int)blockIdx.x >= a.pair_split) != (bool)(turn & 1)) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     {
       f32x16 acc[2][T::NT];
       acc_zero<G, CP>(acc);
@@ -1175,19 +1185,31 @@ hipError_t launch_conv1x1(int C, int which, const Conv1x1Args& a, int grid, hipS
   return hipErrorInvalidValue;
 }
 
-template <int KW, int CIN, int COUT, bool PRE, bool ACT, bool RES, bool DUAL>
-static hipError_t launch_lconv_t(const LConvArgs& a, int n_cu, hipStream_t s) {
-  using G = Geo<2, 64, KW>;
-  const int grid = conv_split_grid(a.npos, 2, COUT / 64, n_cu);
-  constexpr size_t lds = G::ACT_BYTES + ring_bytes(64);
+template <int KW, int CIN, int COUT, bool PRE, bool ACT, bool RES, bool DUAL, int NW>
+static hipError_t launch_lconv_nw(const LConvArgs& a, int n_cu, hipStream_t s) {
+  constexpr int NPOS = NW == 8 ? 2 : 1;
+  using G = Geo<NPOS, 64, KW, NW, (NW == 4 && KW == 3) ? 2 : kKMS>;
+  const int grid = conv_split_grid(a.npos, NPOS, COUT / 64, NW == 8 ? n_cu : 2 * n_cu);   // NW = 4: two workgroups per CU
+  constexpr size_t lds = G::ACT_BYTES + ring_bytes(64, G::KMS);
+  static_assert(NW == 8 || 2 * lds <= 160 * 1024, "two workgroups per CU");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = set_lds(k_lconv<KW, CIN, COUT, PRE, ACT, RES, DUAL>, lds);
+    hipError_t e = set_lds(k_lconv<KW, CIN, COUT, PRE, ACT, RES, DUAL, NW>, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_lconv<KW, CIN, COUT, PRE, ACT, RES, DUAL>), dim3(grid), dim3(kWG), lds, s, a);
+  LConvArgs b = a;
+  b.nms_total = a.nms_total * (kKMS / G::KMS);   // the host counts macro-steps of kKMS k16-steps
+  static const bool turns = getenv("P3HIP_NO_PAIR_TURNS") == nullptr;
+  b.pair_split = (NW == 4 && turns && grid > n_cu) ? n_cu : 0;
+  hipLaunchKernelGGL((k_lconv<KW, CIN, COUT, PRE, ACT, RES, DUAL, NW>), dim3(grid), dim3(NW * 64), lds, s, b);
   return hipGetLastError();
+}
+template <int KW, int CIN, int COUT, bool PRE, bool ACT, bool RES, bool DUAL>
+static hipError_t launch_lconv_t(const LConvArgs& a, int n_cu, hipStream_t s) {
+  static const bool wg8 = getenv("P3HIP_LCONV_WG8") != nullptr;   // 8-wave workgroups, one per CU (A/B timing)
+  if (wg8) return launch_lconv_nw<KW, CIN, COUT, PRE, ACT, RES, DUAL, 8>(a, n_cu, s);
+  return launch_lconv_nw<KW, CIN, COUT, PRE, ACT, RES, DUAL, 4>(a, n_cu, s);
 }
 
 // the layer shapes of the C=384 / C_b=192 btl and nbt blocks and of the C=192 classic blocks

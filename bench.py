@@ -255,9 +255,13 @@ def main():
                 roof["traffic_counters"] = {k: detail[k] for k in ("fetch_size_kib_raw", "write_size_kib")}
             else:
                 roof["traffic_live_unavailable"] = detail
-        roof["launch_contents"] = ("residual blocks + the 1x1 convs of the neighbouring broadcast blocks (HBM-bound, "
-                                   "4.9 % of the FLOPs); blocks_only = the same launches with those convs as their own "
-                                   "launches (P3HIP_NO_BFUSE=1: slower forward pass, comparable with earlier rounds)")
+        if kname.startswith("k_block"):
+            roof["launch_contents"] = ("residual blocks + the 1x1 convs of the neighbouring broadcast blocks (HBM-bound, "
+                                       "4.9 % of the FLOPs); blocks_only = the same launches with those convs as their own "
+                                       "launches (P3HIP_NO_BFUSE=1: slower forward pass, comparable with earlier rounds)")
+        else:
+            roof["launch_contents"] = ("one 3x3 layer conv (C_b -> C_b) of a layer-wise trunk: 4-wave workgroups of one position, "
+                                       "two per CU; activations round-trip HBM between layers")
         if kname.startswith("k_block"):
             os.environ["P3HIP_NO_BFUSE"] = "1"       # read by p3hip_create: this instance only
             try:

@@ -246,7 +246,7 @@ def main():
         if prof:
             roof["algorithmic_bytes_per_launch"] = prof["algorithmic_bytes_per_launch"]
             roof["traffic_source"] = "recorded: " + prof["source"]
-        if not args.no_pmc:
+        if not args.no_pmc and n_gpus == 1:   # counter passes only on a single-GPU run: at N > 1 the recorded figure stands
             prefix = "void p3::k_block<" if kname.startswith("k_block") else "void p3::k_lconv<3,"
             live, detail = measure_hbm_traffic(args.model, args.batch, prefix)
             if live is not None:

@@ -315,26 +315,38 @@ __device__ __forceinline__ void epilogue_math16(EpiOut16<NTn>& eo, f32x4 (&acc)[
   }
 }
 
-template <class G, int COUT_PASS, int NTn>
+__device__ __forceinline__ void half_swap(h4& x, h4& y);   // defined with the HBM epilogues below
+
+// 16-byte LDS stores: ds_write_b64 is banked over 32 banks in groups of 16 consecutive lanes, and a tile's lanes
+// sit 2 rows = 136 dwords apart, so the 8-byte pieces of one instruction fall on 4 banks 4 ways (13.3 LDS cycles
+// per wave-instruction against 5.4 conflict-free, tools/probe/lds_bank_probe.hip; SQ_LDS_BANK_CONFLICT 29 % of the
+// kernel's LDS cycles before).  One v_permlane16_swap per dword (half_swap, as on the way to HBM) turns "my half of
+// two tiles' pieces" into "the whole piece of one row": half as many stores, ds_write_b128 in groups of 8 lanes, 2-way.
+// PIECES: eo already holds (low half, high half) of this lane's row's piece — what a 16-byte global load
+// of the piece layout delivers (stash16) — and goes out as it is.
+template <class G, int COUT_PASS, int NTn, bool PIECES = false>
 __device__ __forceinline__ void epilogue_write16(char* smem, const EpiOut16<NTn>& eo, int cofs) {
   using T = Tiling16<G, COUT_PASS>;
   const int lane = launder(threadIdx.x & 63);
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lg = wid / T::CG;
   const int n = lane & 15, q = lane >> 4;
-  const uint32_t coff = (uint32_t)(((cofs >> 3) + cg_of<G, COUT_PASS>() * 8 + (q >> 1)) * 16 + (q & 1) * 8);
+  const uint32_t coff = (uint32_t)(((cofs >> 3) + cg_of<G, COUT_PASS>() * 8 + (q >> 1)) * 16);
 #pragma unroll
-  for (int j = 0; j < NTn; ++j) {
-    const int t = lg + (j >> 1) * T::LG;
+  for (int b = 0; b < NTn / 2; ++b) {
+    const int t = lg + b * T::LG;
     const int tv = t < G::NT_TOTAL ? t : lg;
     const int p = tv / G::NT_POS, tt = tv - p * G::NT_POS;
-    const int r = tt * 32 + 2 * n + (j & 1);        // row inside its position
+    const int r = tt * 32 + 2 * n + (q & 1);        // this lane's row after the swap: the even tile's (q even) or the odd tile's
     int loc;
     const bool ok = row_valid<G::S>(r, loc) && (t < G::NT_TOTAL);
     const uint32_t dst = (uint32_t)((p * G::PSLOTS + G::PADTOP + r) * G::SLOTB) + coff;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-      if (ok) *(h4*)(smem + dst + ct * 32) = eo.o[j][ct];
+    for (int ct = 0; ct < 4; ++ct) {
+      h4 lo = eo.o[2 * b][ct], hi = eo.o[2 * b + 1][ct];
+      if (!PIECES) half_swap(lo, hi);   // every lane takes part: partners of invalid rows may be valid
+      if (ok) *(h8*)(smem + dst + ct * 32) = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
   }
 }
 

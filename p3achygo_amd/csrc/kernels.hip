@@ -122,9 +122,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
         residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, CB);
         residual_load16<NT>(rr, a.zin);
         stash16<NT>(S, z0);
-        unstash16<NT>(S);
         lds_barrier();   // the act buffer is free: every wave is past the previous position's last segment
-        epilogue_write16<G, CB, NT>(smem, S, 0);
+        epilogue_write16<G, CB, NT, true>(smem, S, 0);
         stash16<NT>(S, rr);   // slice 1 waits raw across the first segment
       }
       ring_note_inflight(ring, 12);
@@ -132,9 +131,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       P3_STAMP(6, 1);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
       P3_STAMP(6, 2);
-      unstash16<NT>(S);
       lds_barrier();
-      epilogue_write16<G, CB, NT>(smem, S, 0);
+      epilogue_write16<G, CB, NT, true>(smem, S, 0);
       residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, 0);
       residual_load16<NT>(rr, a.x);
       ring_note_inflight(ring, 12);
@@ -151,9 +149,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       P3_STAMP(6, 7);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
       P3_STAMP(6, 8);
-      unstash16<NT>(S);
       lds_barrier();
-      epilogue_write16<G, CB, NT>(smem, S, 0);
+      epilogue_write16<G, CB, NT, true>(smem, S, 0);
       residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, CB);
       residual_load16<NT>(rr, a.x);
       ring_note_inflight(ring, 12);

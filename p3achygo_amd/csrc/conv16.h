@@ -361,8 +361,13 @@ __device__ __forceinline__ void epilogue_layer16(char* smem, f32x4 (&acc)[4][NTn
     epi_params16<G, COUT_PASS>(ep, scale, shift, 0);
     epilogue_math16<NTn>(eo, acc, ep);
   }
+  // the lane pairing of the 16-byte stores before the barrier, under the other waves' last K steps
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int b = 0; b < NTn / 2; ++b) half_swap(eo.o[2 * b][ct], eo.o[2 * b + 1][ct]);
   lds_barrier();
-  epilogue_write16<G, COUT_PASS, NTn>(smem, eo, 0);
+  epilogue_write16<G, COUT_PASS, NTn, true>(smem, eo, 0);
 }
 
 // ---- expand epilogue: out = acc + residual -> fp16 global [pos][C/8][361][8] ---------------

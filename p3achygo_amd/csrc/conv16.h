@@ -538,11 +538,24 @@ __device__ __forceinline__ void epilogue_store16_act(f32x4 (&acc)[4][NTn], const
                                                      const float* __restrict__ shift, int cofs) {
   const int q = launder(threadIdx.x & 63) >> 4;
   const int c0 = cofs + cg_of<G, COUT_PASS>() * 64 + q * 4;
+  // the BN parameters of cout tile ct + 1 are requested while tile ct is worked on: the scheduling fence at the
+  // end of an iteration otherwise leaves each tile's two L2 loads exposed
+  // (4-wave kernels only: in the 8-wave C = 256 kernels the eight extra registers spill)
+  constexpr bool PF = G::NW == 4;
+  f32x4 sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0}, nsc = {0, 0, 0, 0}, nsh = {0, 0, 0, 0};
+  if (PF && act) {
+    sc = *(const f32x4*)(scale + c0);
+    sh = *(const f32x4*)(shift + c0);
+  }
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
     char* xc = (char*)x + (size_t)ct * (2 * kNLoc * 8 * 2);
-    f32x4 sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0};
-    if (act) {
+    if (PF) {
+      if (act && ct + 1 < 4) {
+        nsc = *(const f32x4*)(scale + c0 + 16 * (ct + 1));
+        nsh = *(const f32x4*)(shift + c0 + 16 * (ct + 1));
+      }
+    } else if (act) {
       sc = *(const f32x4*)(scale + c0 + 16 * ct);
       sh = *(const f32x4*)(shift + c0 + 16 * ct);
     }
@@ -568,6 +581,10 @@ __device__ __forceinline__ void epilogue_store16_act(f32x4 (&acc)[4][NTn], const
       if (rr.ok[b]) *(h8*)(xc + (uint32_t)(rr.base[b] * 2u)) = piece;
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (PF) {
+      sc = nsc;
+      sh = nsh;
+    }
   }
 }
 

@@ -139,7 +139,7 @@ const char* p3hip_last_error(const p3hip_engine* e);
  *                           the caller undoes exactly as the reference's GetBatch(thread, sym) would have when
  *                           the entry was made — and whether it came from the table.
  * Slots loaded with p3hip_load_slot are evaluated and never cached.  Without p3hip_cache_enable the keyed calls
- * behave as the plain ones (every slot is evaluated; the symmetry reported back is 0, from_cache 0).
+ * behave as the plain ones (every slot is evaluated; the symmetry reported back is the one loaded, from_cache 0).
  * p3hip_cache_stats: lookups, hits, stored entries, table entries. */
 int p3hip_cache_enable(p3hip_engine* e, int log2_entries);
 int p3hip_load_slot_keyed(p3hip_engine* e, int slot, const p3hip_features* f, uint64_t key_lo, uint64_t key_hi,

@@ -238,6 +238,7 @@ struct p3hip_engine {
   float* h_out = nullptr;  // pinned [batch][kResultFloats]
   p3::SlotStates slots;   // dirty flags + slot -> dense row of the last run (slot_state.h)
   int last_n = 0;
+  std::vector<unsigned char> slot_sym, row_sym;   // symmetry given with a keyed load, by slot / by row of the last run
 
   // on-device NN cache (p3hip_cache_enable): the table, the per-slot keys as loaded, and the per-run lists
   struct DeviceCache {
@@ -747,6 +748,8 @@ p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version
   hipMemset(e->d_feats, 0, B * kFeatBytes);
   hipMemset(e->d_out, 0, B * p3::kOutStride * 4);
   e->slots = p3::SlotStates((int)B);
+  e->slot_sym.assign(B, 0);
+  e->row_sym.assign(B, 0);
   return e;
 }
 
@@ -785,6 +788,7 @@ const char* p3hip_last_error(const p3hip_engine* e) { return e->err.c_str(); }
 int p3hip_load_slot(p3hip_engine* e, int slot, const p3hip_features* f) {
   if (slot < 0 || slot >= e->batch) return 1;
   memcpy(e->h_feats + (size_t)slot * kFeatBytes, f, kFeatBytes);
+  e->slot_sym[slot] = 0;
   if (e->cache.on) e->cache.h_slot_keys[slot] = p3::CacheKey{0, 0, 0};   // no key: evaluated, never cached
   e->slots.loaded(slot);
   return 0;
@@ -794,6 +798,7 @@ int p3hip_load_slot_keyed(p3hip_engine* e, int slot, const p3hip_features* f, ui
   if (slot < 0 || slot >= e->batch) return 1;
   if (symmetry < 0 || symmetry > 7) return 1;
   memcpy(e->h_feats + (size_t)slot * kFeatBytes, f, kFeatBytes);
+  e->slot_sym[slot] = (unsigned char)symmetry;
   if (e->cache.on) e->cache.h_slot_keys[slot] = p3::CacheKey{key_lo, key_hi, (unsigned long long)symmetry};
   e->slots.loaded(slot);
   return 0;
@@ -838,6 +843,7 @@ static int gather_loaded(p3hip_engine* e) {
   const bool all = (e->flags & P3HIP_FLAG_RUN_ALL_SLOTS) != 0;
   const int n = e->slots.gather(all, [&](int s, int row) {
     memcpy(e->h_feats_compact + (size_t)row * kFeatBytes, e->h_feats + (size_t)s * kFeatBytes, kFeatBytes);
+    e->row_sym[row] = e->slot_sym[s];
     if (e->cache.on) {
       e->cache.h_keys[row] = e->cache.h_slot_keys[s];
       e->cache.out_row[row] = row;   // p3hip_run re-maps (misses first, then hits)
@@ -970,7 +976,7 @@ int p3hip_get_slot_keyed(p3hip_engine* e, int slot, p3hip_result* out, int* symm
   if (slot < 0 || slot >= e->batch) return 1;
   const int row = e->slots.row(slot), orow = e->out_row_of(slot);
   if (row < 0) return 2;
-  if (symmetry) *symmetry = e->cache.on ? (int)e->cache.h_sym[orow] : 0;
+  if (symmetry) *symmetry = e->cache.on ? (int)e->cache.h_sym[orow] : (int)e->row_sym[row];
   if (from_cache) *from_cache = e->cache.on ? e->cache.was_hit[row] : 0;
   return p3hip_get_slot(e, slot, out);
 }

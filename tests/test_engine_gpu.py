@@ -495,8 +495,13 @@ def test_device_nn_cache_serves_hits_bit_identical_and_evaluates_only_misses(bui
     pos = features.random_positions(96, seed=77, n_games=24)
     ref = engine.HipEngine(path, 96)
     ref.load_all(pos)
+    ref.LoadBatchKeyed(5, pos[5:6], 11, 22, symmetry=6)    # no table: a keyed load is a plain load that remembers its symmetry
     ref.RunInference()
     want = np.stack([ref.get_raw(i) for i in range(96)])
+    _, sym, hit = ref.GetBatchKeyed(5)
+    assert sym == 6 and not hit
+    _, sym, hit = ref.GetBatchKeyed(6)
+    assert sym == 0 and not hit
     ref.close()
     key = lambda i: (0x9E3779B97F4A7C15 * (i + 1) & (2**64 - 1), 0xC2B2AE3D27D4EB4F * (i + 7) & (2**64 - 1))
 

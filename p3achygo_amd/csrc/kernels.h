@@ -121,7 +121,7 @@ struct BDenseArgs {
 };
 
 struct HeadsArgs {
-  const float* hp;  // [npos][96][361]
+  const float* hp;  // [npos][96 / 4][361][4]: channel quads, as k_conv1x1 (EPI 2) stores its accumulators
   float* out;       // [npos][kOutStride]
   int npos;
   int V;

@@ -2,7 +2,7 @@
 //
 // Arithmetic spec: reference python/model.py (cited per kernel).  Layouts:
 //   residual stream / activations in HBM : x[pos][C/8][361][8]  fp16 (channel-blocked)
-//   head pre-activations                  : hp[pos][96][361]     fp32
+//   head pre-activations                  : hp[pos][24][361][4]  fp32 (channel quads)
 //   outputs                               : out[pos][kOutStride] fp32 (see kernels.h)
 // All trunk convs run through conv_core.h (LDS-resident activations, MFMA implicit GEMM,
 // glds weight ring).  One workgroup = 512 threads; grid-stride loop over positions.
@@ -520,13 +520,18 @@ __global__ void __launch_bounds__(kWG, 2) k_conv1x1(Conv1x1Args a) {
           const int p = t / G::NT_POS, tt = t - p * G::NT_POS;
           const int loc = tt * 32 + lr;  // S == 19: row == loc
           if (loc >= kNLoc || pos0 + p >= a.npos) continue;
+          // head activations go out as the accumulator quads they are: hp[pos][c / 4][loc][4] fp32, one 16-byte
+          // store per quad (a wave instruction covers two contiguous 512-byte runs); k_heads reads quads
+          static_assert(COUT % 4 == 0, "channel quads");
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int g4 = 0; g4 < 4; ++g4) {
               const int wid_cg = wid % T::CG;
-              const int c = cp * CP + wid_cg * 64 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-              if (c < COUT) a.out32[((size_t)(pos0 + p) * COUT + c) * kNLoc + loc] = acc[mt][j][i];
+              const int c0 = cp * CP + wid_cg * 64 + mt * 32 + 8 * g4 + 4 * h;   // first channel of the quad
+              if (c0 < COUT)
+                *(f32x4*)(a.out32 + (((size_t)(pos0 + p) * (COUT / 4) + (c0 >> 2)) * kNLoc + loc) * 4) =
+                    f32x4{acc[mt][j][4 * g4], acc[mt][j][4 * g4 + 1], acc[mt][j][4 * g4 + 2], acc[mt][j][4 * g4 + 3]};
             }
         }
       }
@@ -867,32 +872,31 @@ __global__ void __launch_bounds__(1024) k_heads(HeadsArgs a) {
   for (int pos4 = blockIdx.x * L::kGroups; pos4 < a.npos; pos4 += gridDim.x * L::kGroups) {
     const bool live = pos4 + g < a.npos;
     const int pos = live ? pos4 + g : a.npos - 1;   // idle groups recompute the last position
-    const float* __restrict__ hp = a.hp + (size_t)pos * 3 * H * kNLoc;
+    // head activations as channel quads: hp4[(c / 4) * 361 + loc] = channels c .. c + 3 of board point loc
+    // (k_conv1x1's EPI 2); quads 0 .. H/4-1 = p, H/4 .. 2H/4-1 = g, 2H/4 .. 3H/4-1 = v
+    const f32x4* __restrict__ hp4 = (const f32x4*)(a.hp + (size_t)pos * 3 * H * kNLoc);
     float* __restrict__ out = a.out + (size_t)pos * kOutStride;
-    // ---- pooled g (after bn+mish) and pooled v (raw): one wave per channel, two channels
-    // (12 loads) in flight -----------------------------------------------------------------
-    for (int c0 = wid; c0 < 2 * H; c0 += 8) {
-      float v[2][6];
+    // ---- pooled g (after bn+mish) and pooled v (raw): one wave per channel quad, six 16-byte loads in
+    // flight -------------------------------------------------------------------------------------------
+    static_assert(H % 4 == 0, "channel quads");
+    for (int qd = wid; qd < 2 * H / 4; qd += 4) {   // quad of the g / v channels
+      const int c = 4 * qd;                          // g channels are c < H, v channels c >= H
+      const f32x4* src = hp4 + (size_t)(H / 4 + qd) * kNLoc;
+      f32x4 v[6];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int c = c0 + 4 * u;                 // g channels are c < H, v channels c >= H
-        const float* src = hp + (size_t)(H + c) * kNLoc;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const int i = lane + 64 * k;
-          v[u][k] = src[i < kNLoc ? i : kNLoc - 1];
-        }
+      for (int k = 0; k < 6; ++k) {
+        const int i = lane + 64 * k;
+        v[k] = src[i < kNLoc ? i : kNLoc - 1];
       }
+      const bool is_g = c < H;
+      const int ch = is_g ? c : c - H;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int c = c0 + 4 * u;
-        const bool is_g = c < H;
-        const int ch = is_g ? c : c - H;
-        const float bsc = is_g ? hl[L::gbn_scale + ch] : 1.0f, bsh = is_g ? hl[L::gbn_shift + ch] : 0.0f;
+      for (int e = 0; e < 4; ++e) {
+        const float bsc = is_g ? hl[L::gbn_scale + ch + e] : 1.0f, bsh = is_g ? hl[L::gbn_shift + ch + e] : 0.0f;
         float s = 0.0f, m = -3.0e38f;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-          float x = v[u][k];
+          float x = v[k][e];
           if (is_g) x = mish_f(x * bsc + bsh);
           if (lane + 64 * k < kNLoc) {
             s += x;
@@ -903,8 +907,8 @@ __global__ void __launch_bounds__(1024) k_heads(HeadsArgs a) {
         m = wave_max(m);
         if (lane == 0) {
           float* dst = sc + (is_g ? L::gp : L::vp);
-          dst[ch] = s * (1.0f / kNLoc);
-          dst[H + ch] = m;
+          dst[ch + e] = s * (1.0f / kNLoc);
+          dst[H + ch + e] = m;
         }
       }
     }
@@ -961,12 +965,17 @@ __global__ void __launch_bounds__(1024) k_heads(HeadsArgs a) {
       float pi = 0.0f, po = 0.0f, ow = 0.0f;
       const int z = launder(0);   // keeps the LDS weight reads inside the location loop
 #pragma unroll
-      for (int c0 = 0; c0 < H; c0 += 8) {   // 16 loads in flight per round
+      for (int c0 = 0; c0 < H; c0 += 8) {   // four 16-byte loads in flight per round
         float pv[8], vv[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          pv[c] = hp[(size_t)(c0 + c) * kNLoc + i];
-          vv[c] = hp[(size_t)(2 * H + c0 + c) * kNLoc + i];
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 p4 = hp4[(size_t)(c0 / 4 + u) * kNLoc + i];
+          const f32x4 v4 = hp4[(size_t)(2 * H / 4 + c0 / 4 + u) * kNLoc + i];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            pv[4 * u + e] = p4[e];
+            vv[4 * u + e] = v4[e];
+          }
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {

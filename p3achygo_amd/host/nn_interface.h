@@ -147,6 +147,7 @@ class NNInterface final {
   }
   bool device_cache() const { return device_cache_; }
   long device_cache_hits() const { return device_hits_.load(std::memory_order_relaxed); }
+  long device_cache_lookups() const { return device_lookups_.load(std::memory_order_relaxed); }
 
   // Blocks until the result is ready (nn_interface.cc:108-133).
   p3hip_result LoadAndGetInference(int thread_id, const Game& game, Color color_to_move, Probability& prob) {
@@ -354,6 +355,7 @@ class NNInterface final {
     int sym = (int)loaded_sym;
     bool hit = false;
     engine_->GetKeyed(tid, r, &sym, &hit);
+    device_lookups_.fetch_add(1, std::memory_order_relaxed);
     if (hit) device_hits_.fetch_add(1, std::memory_order_relaxed);
     info_[tid].res_ready.store(false, std::memory_order_release);
     NotifyInfer();
@@ -484,7 +486,7 @@ class NNInterface final {
   std::thread infer_thread_;
   int num_cache_last_moves_ = 5;
   bool device_cache_ = false;
-  std::atomic<long> device_hits_{0};
+  std::atomic<long> device_hits_{0}, device_lookups_{0};
   const SignalKind signal_kind_;
   const int num_shared_tasks_;
   int num_signaled_tasks_ = 0, num_exited_tasks_ = 0;

@@ -1128,9 +1128,10 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
 // Thread-per-game drivers: keep the NN cache in the engine's HBM table (p3hip_cache_*, 2^log2_entries entries per
 // engine) instead of NNInterface's per-thread host LRUs; 0 = host caches (the reference's arrangement).
 static std::atomic<int> g_device_nn_cache_log2{0};
-static std::atomic<long> g_device_nn_cache_hits{0};
+static std::atomic<long> g_device_nn_cache_hits{0}, g_device_nn_cache_lookups{0};
 void p3host_set_device_nn_cache(int log2_entries) { g_device_nn_cache_log2.store(log2_entries < 0 ? 0 : log2_entries); }
 long p3host_device_nn_cache_hits() { return g_device_nn_cache_hits.load(); }   // of the last thread-per-game match
+long p3host_device_nn_cache_lookups() { return g_device_nn_cache_lookups.load(); }
 
 int p3host_eval_match_threads(const char* engine_lib, const char* cur_weights, const char* cand_weights, int device,
                               int num_games, int visits_per_move, int threads_per_game, int max_moves,
@@ -1226,6 +1227,7 @@ int p3host_eval_match_threads(const char* engine_lib, const char* cur_weights, c
     });
   for (auto& t : threads) t.join();
   g_device_nn_cache_hits.store(nn[0]->device_cache_hits() + nn[1]->device_cache_hits());
+  g_device_nn_cache_lookups.store(nn[0]->device_cache_lookups() + nn[1]->device_cache_lookups());
   if (out) {
     std::memset(out, 0, sizeof *out);
     FinishEvalMatch(outcomes, out);

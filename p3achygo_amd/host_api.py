@@ -341,6 +341,12 @@ def device_nn_cache_hits() -> int:
     return int(L.p3host_device_nn_cache_hits())
 
 
+def device_nn_cache_lookups() -> int:
+    L = lib()
+    L.p3host_device_nn_cache_lookups.restype = C.c_long
+    return int(L.p3host_device_nn_cache_lookups())
+
+
 def eval_match_threads(cur_weights: str | None, cand_weights: str | None, num_games: int, visits_per_move: int = 128,
                        threads_per_game: int = 8, max_moves: int = 600, cache_size: int = 1 << 20, seed: int = 1,
                        device: int = 0, engine_lib: str | None = None) -> EvalStats:

@@ -255,6 +255,12 @@ class EvalGame {
     if (parallel_) search_.Deliver(i, r);
     else puct_.Resume(r);
   }
+  // the engine's NN cache answered (or evaluated) under symmetry `sym`, which need not be the one FillEval drew
+  Symmetry eval_symmetry(int i) const { return sym_[i]; }
+  void DeliverUnder(int i, p3hip_result& r, Symmetry sym) {
+    sym_[i] = sym;
+    Deliver(i, r);
+  }
   // +1 cur won, -1 cand won, 0 draw
   int cur_result() const {
     const Color w = winner_;

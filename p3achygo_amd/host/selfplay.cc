@@ -175,6 +175,23 @@ class EvalCache {
       return true;
     }
   };
+  // 128-bit digest of a key for the engine's HBM table (two independent mixes of the same fields)
+  static void Digest(const Key& k, uint64_t* lo, uint64_t* hi) {
+    uint32_t kb;
+    std::memcpy(&kb, &k.komi, 4);
+    uint64_t a = k.hash ^ (uint64_t(uint8_t(k.color)) * 0x9e3779b97f4a7c15ull);
+    uint64_t b = (k.hash * 0xd6e8feb86659fd93ull) ^ (uint64_t(kb) << 8) ^ uint64_t(uint8_t(k.color));
+    for (const Loc& l : k.last) {
+      const uint64_t m = uint64_t(uint32_t(l.i * 32 + l.j + 64));
+      a = (a ^ m) * 0xff51afd7ed558ccdull;
+      b = ((b << 7) | (b >> 57)) ^ (m * 0xc2b2ae3d27d4eb4full);
+    }
+    a = (a ^ kb) * 0xc4ceb9fe1a85ec53ull;
+    b = (b ^ (b >> 31)) * 0x94d049bb133111ebull;
+    *lo = a ^ (a >> 29);
+    *hi = b ^ (b >> 32);
+    if ((*lo | *hi) == 0) *lo = 1;
+  }
   Key MakeKey(const Position& pos, Color c) const {   // NNInterface::MakeKey, nn_interface.cc:92-106
     Key k{pos.board.hash(), {kNoopLoc, kNoopLoc, kNoopLoc, kNoopLoc, kNoopLoc}, pos.komi(), c};
     for (int i = 5 - nlast_; i < 5; ++i) k.last[i] = pos.last[i].loc;
@@ -989,6 +1006,16 @@ static std::string EvalGameSgf(const Game& game, bool cur_is_black, bool resigne
                        cur_is_black ? "cand" : "cur");
 }
 
+// Evaluation-match drivers: keep the NN cache in the engine's HBM table (p3hip_cache_*, 2^log2_entries entries per
+// engine: one table for all games and workers of a player) — instead of NNInterface's per-thread host LRUs in the
+// thread-per-game driver, behind the per-game host caches in the batching one; 0 = host caches only (the reference's
+// arrangement).
+static std::atomic<int> g_device_nn_cache_log2{0};
+static std::atomic<long> g_device_nn_cache_hits{0}, g_device_nn_cache_lookups{0};
+void p3host_set_device_nn_cache(int log2_entries) { g_device_nn_cache_log2.store(log2_entries < 0 ? 0 : log2_entries); }
+long p3host_device_nn_cache_hits() { return g_device_nn_cache_hits.load(); }   // of the last thread-per-game match
+long p3host_device_nn_cache_lookups() { return g_device_nn_cache_lookups.load(); }
+
 // Plays `num_games` evaluation games between two networks with the batch parallel search
 // (eval.cc:103-518).  engine_lib NULL/"" = NullEvaluator for both players.  One engine
 // instance per player, batch = num_games * leaves_per_round slots; every game keeps an NN cache
@@ -1014,6 +1041,16 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
       }
     }
   }
+  const int dc_log2 = g_device_nn_cache_log2.load();
+  bool device_cache = false;
+  if (dc_log2 > 0 && !use_null) {
+    device_cache = ev[0]->EnableDeviceCache(dc_log2) && ev[1]->EnableDeviceCache(dc_log2);
+    if (!device_cache) {
+      if (err) snprintf(err, 256, "the engine has no on-device NN cache (p3hip_cache_enable)");
+      return 1;
+    }
+  }
+  std::atomic<long> device_lookups{0}, device_hits{0};
   std::vector<std::unique_ptr<EvalGame>> games;
   for (int g = 0; g < num_games; ++g)
     games.emplace_back(new EvalGame(g, pc[0], pc[1], max_moves, seed * 0x9E3779B97F4A7C15ull + (uint64_t)g * 0xBF58476D1CE4E5B9ull));
@@ -1069,7 +1106,13 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
       for (int i = 0; i < want[g]; ++i) {
         if (slot_of[g][i] < 0) continue;
         games[g]->FillEval(i, f + slot_of[g][i]);
-        ev[e]->Load(base[g] + slot_of[g][i], f[slot_of[g][i]]);
+        if (device_cache) {
+          uint64_t lo, hi;
+          EvalCache::Digest(key_of[g][i], &lo, &hi);
+          ev[e]->LoadKeyed(base[g] + slot_of[g][i], f[slot_of[g][i]], lo, hi, (int)games[g]->eval_symmetry(i));
+        } else {
+          ev[e]->Load(base[g] + slot_of[g][i], f[slot_of[g][i]]);
+        }
       }
     });
     bool ok[2] = {true, true};
@@ -1094,8 +1137,17 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
           cache_hits.fetch_add(1, std::memory_order_relaxed);
           continue;
         }
-        ev[e]->Get(base[g] + slot_of[g][i], r);
-        games[g]->Deliver(i, r);   // un-symmetrises r in place
+        if (device_cache) {
+          int sym = (int)games[g]->eval_symmetry(i);
+          bool hit = false;
+          ev[e]->GetKeyed(base[g] + slot_of[g][i], r, &sym, &hit);
+          device_lookups.fetch_add(1, std::memory_order_relaxed);
+          if (hit) device_hits.fetch_add(1, std::memory_order_relaxed);
+          games[g]->DeliverUnder(i, r, (Symmetry)sym);   // un-symmetrises by the symmetry of the stored result
+        } else {
+          ev[e]->Get(base[g] + slot_of[g][i], r);
+          games[g]->Deliver(i, r);   // un-symmetrises r in place
+        }
         cache.Insert(key_of[g][i], r);
       }
       advance(g);
@@ -1115,6 +1167,8 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
     out->positions = positions;
     out->batches = batches;
     out->cache_hits = cache_hits.load();
+    g_device_nn_cache_hits.store(device_hits.load());
+    g_device_nn_cache_lookups.store(device_lookups.load());
     out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
   return 0;
@@ -1125,14 +1179,6 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
 // num_shared_search_tasks = num_games, batch = num_games * threads_per_game slots and the
 // per-thread NN cache on (cache_size entries in total per interface), the side to move running
 // the threaded mcts::Search (threaded_search.h) on slot range [game * T, (game + 1) * T).
-// Thread-per-game drivers: keep the NN cache in the engine's HBM table (p3hip_cache_*, 2^log2_entries entries per
-// engine) instead of NNInterface's per-thread host LRUs; 0 = host caches (the reference's arrangement).
-static std::atomic<int> g_device_nn_cache_log2{0};
-static std::atomic<long> g_device_nn_cache_hits{0}, g_device_nn_cache_lookups{0};
-void p3host_set_device_nn_cache(int log2_entries) { g_device_nn_cache_log2.store(log2_entries < 0 ? 0 : log2_entries); }
-long p3host_device_nn_cache_hits() { return g_device_nn_cache_hits.load(); }   // of the last thread-per-game match
-long p3host_device_nn_cache_lookups() { return g_device_nn_cache_lookups.load(); }
-
 int p3host_eval_match_threads(const char* engine_lib, const char* cur_weights, const char* cand_weights, int device,
                               int num_games, int visits_per_move, int threads_per_game, int max_moves,
                               long cache_size, uint64_t seed, p3host_eval_stats* out, char* err) {

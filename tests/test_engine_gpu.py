@@ -398,13 +398,23 @@ def test_thread_per_game_match_with_the_nn_cache_in_hbm(built, weight_files):
     from p3achygo_amd import host_api
     host_api.set_device_nn_cache(14)
     try:
-        st = host_api.eval_match_threads(weight_files("test_b3c128btl2"), weight_files("test_b3c128nbt"), num_games=6,
+        weights = weight_files
+        st = host_api.eval_match_threads(weights("test_b3c128btl2"), weights("test_b3c128nbt"), num_games=6,
                                          visits_per_move=24, threads_per_game=4, max_moves=16, cache_size=0, seed=5)
     finally:
         host_api.set_device_nn_cache(0)
     assert st.games == 6 and st.cur_wins + st.cand_wins + st.draws == 6 and st.moves > 6
     lookups, hits = host_api.device_nn_cache_lookups(), host_api.device_nn_cache_hits()
     assert lookups > 100 and 0 <= hits < lookups
+    # the batching scheduler's match puts the same tables behind its per-game host caches
+    host_api.set_device_nn_cache(12)
+    try:
+        st = host_api.eval_match(weights("test_b3c128btl2"), weights("test_b3c128nbt"), num_games=6, visits_per_move=16,
+                                 leaves_per_round=4, max_moves=16, num_threads=4, seed=5)
+    finally:
+        host_api.set_device_nn_cache(0)
+    assert st.games == 6 and st.cur_wins + st.cand_wins + st.draws == 6
+    assert host_api.device_nn_cache_lookups() == st.positions and 0 <= host_api.device_nn_cache_hits() < st.positions
 
 
 @pytest.mark.gpu

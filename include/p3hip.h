@@ -95,6 +95,9 @@ typedef struct p3hip_engine p3hip_engine;
 #define P3HIP_FLAG_NONE 0u
 #define P3HIP_FLAG_RUN_ALL_SLOTS 2u /* always run the full static batch (TRT behaviour,
                                        trt_engine.cc:238-304); default compacts to loaded slots */
+#define P3HIP_FLAG_SHARED_DEVICE 4u /* several engines keep this GPU busy at once (the self-play host's game groups, the
+                                       two players of a match): launches leave out the start-up stagger that only pays
+                                       when a launch has the GPU to itself */
 
 /* Creates an engine from a `.p3w` weight file (see p3achygo_amd/netspec.py) for a static
  * batch of `batch_size` slots on HIP device `device_ordinal`.  `version` is the model

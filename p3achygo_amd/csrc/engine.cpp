@@ -564,7 +564,10 @@ p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
     // per launch, so short launches go without.  P3HIP_STAGGER overrides (0 = off).
     static const int stagger_env = getenv("P3HIP_STAGGER") ? atoi(getenv("P3HIP_STAGGER")) : -1;
     const bool long_launch = npos >= 3 * e->n_cu * (e->wf.C == 256 || e->c128_wg8 ? 1 : 2);
-    a.stagger = stagger_env >= 0 ? stagger_env : ((a.head || a.tail) && long_launch ? 10000 : 0);
+    // (engines sharing the GPU with others: the spread costs its own length and another stream's kernels fill a
+    // launch's tail anyway — 0.3-0.6 % of the self-play rate, gpurun_out/stagger_selfplay.log)
+    const bool shared = (e->flags & P3HIP_FLAG_SHARED_DEVICE) != 0;
+    a.stagger = stagger_env >= 0 ? stagger_env : ((a.head || a.tail) && long_launch && !shared ? 10000 : 0);
     // two 4-wave workgroups per CU and at least two positions each: they take turns at the higher wave
     // priority (kernels.h; b12c128btl3 forward -3.5 %, b8c128nbt -2.5 % at 1024 positions, nothing at 512 and
     // below; profiles/r02_c128_pair_turns.txt).  P3HIP_NO_PAIR_TURNS=1 leaves the priorities alone.

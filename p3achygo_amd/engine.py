@@ -32,6 +32,7 @@ EXPORTS = [
 ]
 
 FLAG_RUN_ALL_SLOTS = 2
+FLAG_SHARED_DEVICE = 4
 
 
 class EngineError(RuntimeError):

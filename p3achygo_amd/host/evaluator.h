@@ -68,7 +68,7 @@ struct HipEvaluator final : Evaluator {
   decltype(&p3hip_cache_stats) cache_stats = nullptr;
   std::string err;
 
-  bool Open(const char* lib_path, const char* weights, int batch, int device) {
+  bool Open(const char* lib_path, const char* weights, int batch, int device, uint32_t flags = 0) {
     lib = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
     if (!lib) { err = dlerror(); return false; }
     create = (decltype(create))dlsym(lib, "p3hip_create");
@@ -84,7 +84,7 @@ struct HipEvaluator final : Evaluator {
     get_keyed = (decltype(get_keyed))dlsym(lib, "p3hip_get_slot_keyed");
     cache_stats = (decltype(cache_stats))dlsym(lib, "p3hip_cache_stats");
     if (!create || !destroy || !load || !run || !get) { err = "missing p3hip symbols"; return false; }
-    eng = create(weights, batch, 1, device, 0);
+    eng = create(weights, batch, 1, device, flags);
     if (!eng) { err = create_error ? create_error() : "p3hip_create failed"; return false; }
     return true;
   }

@@ -739,7 +739,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     } else {
       auto* e = new HipEvaluator();
       halves[h].eval.reset(e);
-      if (!e->Open(engine_lib, weights, ng, device)) {
+      if (!e->Open(engine_lib, weights, ng, device, P3HIP_FLAG_SHARED_DEVICE)) {   // one engine per game group, all on this GPU
         if (err) snprintf(err, 256, "%s", e->err.c_str());
         return 1;
       }
@@ -1035,7 +1035,7 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
     } else {
       auto* h = new HipEvaluator();
       ev[e].reset(h);
-      if (!h->Open(engine_lib, e == 0 ? cur_weights : cand_weights, slots, device)) {
+      if (!h->Open(engine_lib, e == 0 ? cur_weights : cand_weights, slots, device, P3HIP_FLAG_SHARED_DEVICE)) {   // the two players' passes run concurrently
         if (err) snprintf(err, 256, "%s", h->err.c_str());
         return 1;
       }
@@ -1194,7 +1194,7 @@ int p3host_eval_match_threads(const char* engine_lib, const char* cur_weights, c
     } else {
       auto* h = new HipEvaluator();
       ev.reset(h);
-      if (!h->Open(engine_lib, e == 0 ? cur_weights : cand_weights, batch, device)) {
+      if (!h->Open(engine_lib, e == 0 ? cur_weights : cand_weights, batch, device, P3HIP_FLAG_SHARED_DEVICE)) {
         if (err) snprintf(err, 256, "%s", h->err.c_str());
         return 1;
       }

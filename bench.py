@@ -9,13 +9,21 @@ Headline (BASELINE.json metric): leaf positions evaluated 
 b12c256btl3 weights, 1024 positions per engine batch (BASELINE.json configs[2]).  One "step" = one
 engine batch (`p3hip_run` over one group of 1024 games' leaf positions); the host keeps GROUPS
 groups in flight (GROUPS - 1 forward passes queued on the GPU while one group is on the host).
-W warm-up rounds (one batch per group each) run untimed, then exactly K steps are timed inside the
-host (its own steady clock around the rounds, engine streams drained at the end), bracketed by
+Untimed: an advance phase that plays every game past its raw-policy opening (up to 30 moves of ONE
+evaluation each, self_play_thread.cc:44,363-366; at most --advance-limit batches per group), so that
+the timed steps are steady-state Gumbel n=32 search whatever K is, then W warm-up rounds (one batch per
+group each).  Then exactly K steps are timed inside the host: the window opens at the completion of the
+last warm-up batch and closes at the completion of the K-th engine batch after it, whichever groups those
+batches fall in (its own steady clock; every engine run ends with its stream drained), bracketed by
 barriers; the slowest rank's time is the job's time.  Games shard embarrassingly across GPUs (one
 process, one engine set, one HIP stream set per device; no data-path collective): weak scaling.
+`--gpus N` without WORLD_SIZE in the environment starts the N rank processes itself (before anything
+touches the GPU); under torch.distributed.run it checks N against WORLD_SIZE.
 
 Secondary figures in the same JSON line:
   engine_only  — forward pass alone over a resident batch (no host, no PCIe);
+  engine_benchmark — the reference's nn::Benchmark loop (benchmark_engine.cc:77-108) from C++ over the C ABI;
+  as_stated_c3 — BASELINE configs[2] as written: ONE group of 1024 games, batch 1024;
   roofline     — dominant kernel k_block: conv FLOPs (3x3s + 1x1 reduce/expand) per launch / HIP-event
                  time on the engine's stream, against the 2.5 PFLOP/s dense fp16 MFMA peak;
   cpu_baseline — the CPU fp32 oracle on this box's host cores over a bounded sample: engine-only
@@ -69,26 +77,31 @@ def cpu_baseline(path, pos, model, budget_s=10.0):
            "what": "engine only: CPU fp32 oracle forward pass, no search",
            "sample": f"{n} positions of the same batch, {model} fp32 direct conv, {dt:.1f}s"}
     # the same self-play host, the CPU engine bound through the same C ABI:
-    # 2 groups x 4*cores games; the engine's forward pass gets all cores while a group is evaluated
+    # 2 groups x `cores` games (every batch gives each core one position), the same advance past the
+    # raw-policy openings as the headline run, then the measured batches
     try:
         cpu_lib = os.path.join(ROOT, "oracle", "libp3cpu_engine.so")
         os.environ["P3CPU_THREADS"] = str(cores)
-        games = 2 * 4 * cores
+        games = 2 * cores
         per_batch_s = (games / 2) / max(out["value"], 1e-9)
-        rounds = max(2, int(budget_s / max(2 * per_batch_s, 1e-3)))
+        steps = max(4, int(budget_s / max(per_batch_s, 1e-3)))
         host_api.set_groups(2)
-        host_api.set_step_limit(2 * rounds)
+        host_api.set_step_limit(steps)
+        host_api.set_advance_limit(32)
         st = host_api.selfplay_run(path, games, cores, 0.0, default_n=32, default_k=5, selected_n=32, selected_k=5,
                                    warmup_batches=1, seed=77, engine_lib=cpu_lib)
         out["selfplay"] = {"value": st.positions / st.seconds, "unit": "positions/s", "cores": cores,
                            "what": "the same self-play host (Gumbel n=32) over the CPU fp32 engine through the "
                                    "same C ABI (oracle/libp3cpu_engine.so)",
+                           "evals_per_move": st.positions / max(st.moves, 1),
+                           "games_past_opening": st.games_past_opening, "advance_batches_untimed": st.advance_batches,
                            "sample": f"{games} concurrent games, {st.batches} engine batches of {games // 2}, "
                                      f"{st.positions} positions, {st.seconds:.1f}s"}
     except Exception as ex:   # noqa: BLE001
         out["selfplay"] = {"error": repr(ex)}
     finally:
         host_api.set_step_limit(0)
+        host_api.set_advance_limit(0)
     return out
 
 
@@ -149,6 +162,37 @@ def measure_hbm_traffic(model, batch, kernel_prefix):
                    "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two child runs of 3 forward passes; reads = 2 x FETCH_SIZE (gfx950 half-count of 16-byte accesses); mean over the kernel's launches"}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N rank processes here,
+    one per GPU (the reference starts one self-play process per GPU: python/rl_loop/sp_loop.py:160-192,
+    selfplay.py:51-64).  Nothing in this parent has touched torch or the GPU.  Rank 0's child prints the
+    JSON line on the inherited stdout; the first failing rank takes the others down with it."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in live:      # a dead rank leaves the others in a barrier: end exactly the ones started here
+                    other.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,13 +201,29 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--groups", type=int, default=DEFAULT_GROUPS, help="game groups (engine instances / HIP streams) per GPU")
     ap.add_argument("--model", default=MODEL)
+    ap.add_argument("--advance-limit", type=int, default=64,
+                    help="untimed batches per group, at most, that play every game past its raw-policy opening "
+                         "before the warm-up (0 = start timing inside the openings, as rounds 1-2 did)")
     ap.add_argument("--engine-steps", type=int, default=200, help="timed steps of the engine-only leg")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic measurement (two rocprofv3 --pmc child runs)")
     ap.add_argument("--ladder-budget", type=int, default=LADDER_BUDGET,
                     help="ladder read-out work bound of the self-play host (0 = reference-exact, the default; "
                          "> 0 = the opt-in throughput mode, hits are reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the engine_benchmark and as_stated_c3 legs")
+    ap.add_argument("--null-engine", action="store_true",
+                    help="plumbing rehearsal without a GPU: the host over its NullEvaluator (uniform policy); "
+                         "the line it prints is marked as not a measurement")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch one rank per GPU "
+                 f"(torch.distributed.run --nproc-per-node {args.gpus}) or drop WORLD_SIZE and let bench.py start them")
 
     from p3achygo_amd import sharding
     shard = sharding.shard_from_env()
@@ -173,47 +233,95 @@ def main():
     import torch
     sharding.init(shard)
     n_gpus = max(world, 1)
+    use_gpu = not args.null_engine
+    if use_gpu and local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank} but the node shows {torch.cuda.device_count()}")
     # host cores of this rank: its share of the allowed cores, on its GPU's NUMA node when known
     bus_ids = None
     try:
         bus_ids = []
-        for d in range(torch.cuda.device_count()):
+        for d in range(torch.cuda.device_count() if use_gpu else 0):
             p = torch.cuda.get_device_properties(d)
             bus_ids.append(f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0")
     except Exception:   # noqa: BLE001
         bus_ids = None
     cpus = sharding.bind_rank_to_local_cpus(shard, bus_ids)
 
-    from p3achygo_amd import engine, host_api, netspec
+    from p3achygo_amd import host_api, netspec
     cfg = netspec.CONFIGS[args.model]
     tmp = tempfile.mkdtemp(prefix="p3bench")
     path = os.path.join(tmp, f"{args.model}.p3w")
-    netspec.save_p3w(path, cfg, netspec.generate_weights(cfg))  # fresh-Keras random init
-    pos = make_positions(args.batch, seed=1000 + rank)
-    torch.cuda.set_device(local_rank)
+    if use_gpu:
+        from p3achygo_amd import engine
+        netspec.save_p3w(path, cfg, netspec.generate_weights(cfg))  # fresh-Keras random init
+        pos = make_positions(args.batch, seed=1000 + rank)
+        torch.cuda.set_device(local_rank)
+
+    def sync():
+        if use_gpu:
+            torch.cuda.synchronize()
 
     # ---- headline: self-play through the C ABI ----------------------------------------------
     threads = max(2, min(16, len(cpus)))
     GROUPS = args.groups   # local from here on
-    steps = ((args.steps + GROUPS - 1) // GROUPS) * GROUPS     # whole rounds
+    steps = args.steps
     host_api.set_groups(GROUPS)
     host_api.set_ladder_budget(args.ladder_budget)
     host_api.set_step_limit(steps)
+    host_api.set_advance_limit(args.advance_limit)
     ladder0 = host_api.ladder_stats()
     sharding.barrier(shard)
-    torch.cuda.synchronize()
+    sync()
     wall0 = time.perf_counter()
-    st = host_api.selfplay_run(path, GROUPS * args.batch, threads, 0.0, default_n=32, default_k=5, selected_n=32,
-                               selected_k=5, warmup_batches=args.warmup, seed=sharding.seed_for_rank(77, shard),
-                               device=local_rank)
-    torch.cuda.synchronize()
+    st = host_api.selfplay_run(path if use_gpu else None, GROUPS * args.batch, threads, 0.0, default_n=32, default_k=5,
+                               selected_n=32, selected_k=5, warmup_batches=args.warmup,
+                               seed=sharding.seed_for_rank(77, shard), device=local_rank)
+    sync()
     wall = time.perf_counter() - wall0
     host_api.set_step_limit(0)
+    host_api.set_advance_limit(0)
     ladder1 = host_api.ladder_stats()
     dt = sharding.max_over_ranks(shard, st.seconds)
     sharding.barrier(shard)
     totals = sharding.sum_over_ranks(shard, [st.positions, st.moves, st.games, st.batches, st.cache_hits,
-                                             ladder1[0] - ladder0[0], ladder1[3] - ladder0[3]])
+                                             ladder1[0] - ladder0[0], ladder1[3] - ladder0[3],
+                                             st.games_past_opening, st.advance_batches])
+
+    def headline():
+        pps = totals[0] / dt
+        return {
+            "metric": "self-play positions/sec at 1/8 MI355X, b12c256btl3 19x19 n=32",
+            "value": pps, "unit": "positions/s", "n_gpus": n_gpus, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{args.model} random-init, self-play: C++ host (Gumbel MCTS n=32, default k<=5, "
+                                   f"selected k=5) -> p3hip_run over batches of {args.batch} leaf positions -> "
+                                   "results back to the search; one step = one engine batch",
+                       "batch_per_gpu": args.batch, "concurrent_games_per_gpu": GROUPS * args.batch,
+                       "game_groups_per_gpu": GROUPS, "host_threads_per_gpu": threads,
+                       "host_cpus_of_rank0": [cpus[0], cpus[-1]] if cpus else None,
+                       "ladder_node_budget": args.ladder_budget,
+                       "parallelism": f"games sharded x{n_gpus}, no collective"},
+            "includes": "host MCTS + PCIe (1,860 B up / 7,556 B down per position) + engine",
+            "positions": totals[0], "moves_per_s": totals[1] / dt,
+            "evals_per_move": totals[0] / max(totals[1], 1.0),
+            "games_past_opening": totals[7], "games_total": n_gpus * GROUPS * args.batch,
+            "advance_batches_untimed": totals[8],
+            "finished_games": totals[2],
+            "engine_batches_completed": totals[3], "mean_batch_fill": totals[0] / max(steps * n_gpus, 1) / args.batch,
+            "eval_cache_hits": totals[4], "ladder_readouts": totals[5], "ladder_budget_hits": totals[6],
+            "seconds_timed": dt, "wall_s_incl_setup_advance_and_warmup": wall,
+        }
+
+    if not use_gpu:
+        if rank == 0:
+            out = headline()
+            out["engine"] = "NullEvaluator (uniform policy): a plumbing rehearsal of the launch path, NOT a measurement"
+            out["roofline"] = out["cpu_baseline"] = None
+            print(json.dumps(out), flush=True)
+        sharding.finish(shard)
+        return
 
     # ---- secondary: the engine alone over a resident batch ----------------------------------
     eng = engine.create_engine(engine.kind_from_engine_path(path), path, args.batch, 1, device=local_rank)
@@ -234,6 +342,7 @@ def main():
 
     roof = None
     cpu = None
+    extras = {}
     if rank == 0:
         ms, flops_launch, kname = eng.time_trunk_kernel(args.batch, 10)
         achieved = flops_launch / (ms * 1e-3) / 1e12
@@ -278,6 +387,39 @@ def main():
             finally:
                 del os.environ["P3HIP_NO_BFUSE"]
     eng.close()
+    if rank == 0 and n_gpus == 1 and not args.no_extras:
+        # the reference's engine micro-benchmark, from C++
+        try:
+            eb = host_api.engine_benchmark(path, pos, args.batch, warmup_runs=100, max_rounds=1001, device=local_rank)
+            extras["engine_benchmark"] = {
+                "value": args.batch / (eb.avg_run_us * 1e-6), "unit": "positions/s", "avg_run_us": eb.avg_run_us,
+                "rounds": eb.rounds, "loop_positions_per_s": eb.positions / eb.loop_seconds,
+                "what": "nn::Benchmark (benchmark_engine.cc:77-108) in C++ over the C ABI on one thread: 100 warm-up runs, "
+                        f"{eb.rounds} rounds of p3hip_load_slot x {args.batch} -> p3hip_run -> p3hip_get_slot x {args.batch}; "
+                        "value = batch / mean p3hip_run time (H2D + forward pass + D2H, the reference's clock placement); "
+                        "loop_positions_per_s also counts the loads and gets"}
+        except Exception as ex:   # noqa: BLE001
+            extras["engine_benchmark"] = {"error": repr(ex)}
+        # BASELINE configs[2] exactly as written: 1024 concurrent games, batch 1024 = ONE game group, so the
+        # GPU idles while the host advances the games and the host idles during the forward pass
+        try:
+            host_api.set_groups(1)
+            host_api.set_step_limit(512)
+            host_api.set_advance_limit(args.advance_limit)
+            s1 = host_api.selfplay_run(path, args.batch, threads, 0.0, default_n=32, default_k=5, selected_n=32,
+                                       selected_k=5, warmup_batches=8, seed=177, device=local_rank)
+            extras["as_stated_c3"] = {
+                "value": s1.positions / s1.seconds, "unit": "positions/s", "steps": s1.batches,
+                "concurrent_games": args.batch, "game_groups": 1, "evals_per_move": s1.positions / max(s1.moves, 1),
+                "gpu_share_of_time": s1.gpu_seconds / s1.seconds, "host_share_of_time": s1.host_seconds / s1.seconds,
+                "what": "BASELINE configs[2] as stated (1024 concurrent games, inference batch 1024): one game group, "
+                        "host and GPU alternate; the headline keeps `game_groups_per_gpu` groups in flight instead"}
+        except Exception as ex:   # noqa: BLE001
+            extras["as_stated_c3"] = {"error": repr(ex)}
+        finally:
+            host_api.set_groups(GROUPS)
+            host_api.set_step_limit(0)
+            host_api.set_advance_limit(0)
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline(path, pos, args.model)
@@ -286,36 +428,19 @@ def main():
     sharding.barrier(shard)
 
     if rank == 0:
-        pps = totals[0] / dt
+        out = headline()
+        pps = out["value"]
         eng_pps = n_gpus * args.batch * args.engine_steps / dt_e
-        out = {
-            "metric": "self-play positions/sec at 1/8 MI355X, b12c256btl3 19x19 n=32",
-            "value": pps, "unit": "positions/s", "n_gpus": n_gpus, "steps": steps,
-            "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{args.model} random-init, self-play: C++ host (Gumbel MCTS n=32, default k<=5, "
-                                   f"selected k=5) -> p3hip_run over batches of {args.batch} leaf positions -> "
-                                   "results back to the search; one step = one engine batch",
-                       "batch_per_gpu": args.batch, "concurrent_games_per_gpu": GROUPS * args.batch,
-                       "game_groups_per_gpu": GROUPS, "host_threads_per_gpu": threads,
-                       "host_cpus_of_rank0": [cpus[0], cpus[-1]] if cpus else None,
-                       "ladder_node_budget": args.ladder_budget,
-                       "parallelism": f"games sharded x{n_gpus}, no collective"},
-            "includes": "host MCTS + PCIe (1,860 B up / 7,556 B down per position) + engine",
-            "positions": totals[0], "moves_per_s": totals[1] / dt, "finished_games": totals[2],
-            "engine_batches_completed": totals[3], "mean_batch_fill": totals[0] / max(steps * n_gpus, 1) / args.batch,
-            "eval_cache_hits": totals[4], "ladder_readouts": totals[5], "ladder_budget_hits": totals[6],
-            "seconds_timed": dt, "wall_s_incl_setup_and_warmup": wall,
-            "conv3x3_mfma_frac_end_to_end": pps * conv3_flops / 1e12 / (PEAK_FP16_MFMA_TFLOPS * n_gpus),
-            "engine_only": {"value": eng_pps, "unit": "positions/s", "steps": args.engine_steps,
-                            "ms_per_step": dt_e / args.engine_steps * 1e3,
-                            "what": "forward pass over a resident batch: no host, no PCIe",
-                            "full_net_tflops": eng_pps * total_flops / 1e12,
-                            "conv3x3_mfma_frac": eng_pps * conv3_flops / 1e12 / (PEAK_FP16_MFMA_TFLOPS * n_gpus)},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        print(json.dumps(out))
+        out["conv3x3_mfma_frac_end_to_end"] = pps * conv3_flops / 1e12 / (PEAK_FP16_MFMA_TFLOPS * n_gpus)
+        out["engine_only"] = {"value": eng_pps, "unit": "positions/s", "steps": args.engine_steps,
+                              "ms_per_step": dt_e / args.engine_steps * 1e3,
+                              "what": "forward pass over a resident batch: no host, no PCIe",
+                              "full_net_tflops": eng_pps * total_flops / 1e12,
+                              "conv3x3_mfma_frac": eng_pps * conv3_flops / 1e12 / (PEAK_FP16_MFMA_TFLOPS * n_gpus)}
+        out.update(extras)
+        out["roofline"] = roof
+        out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
     sharding.finish(shard)
 
 

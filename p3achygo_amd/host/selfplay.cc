@@ -259,6 +259,9 @@ class GameRunner {
   }
   const GameStats& stats() const { return stats_; }
   const Game& game() const { return *game_; }
+  // false while the game still samples its opening from the raw policy (one evaluation per move,
+  // self_play_thread.cc:44,363-366): the scheduler's advance phase plays every game past it
+  bool past_opening() const { return game_->num_moves() >= num_moves_raw_policy_; }
   const std::vector<Move>& last_moves() const { return last_moves_; }
   const Game::Result& last_result() const { return last_result_; }
 
@@ -604,8 +607,8 @@ struct Half {
   bool ok = true;
   double gpu_seconds = 0, host_seconds = 0;   // inside Run / inside advance, measured region only
   long measured_batches = 0;
-  GameStats base, end;                         // game counters at the start / end of the measured region
-  std::chrono::steady_clock::time_point t_start, t_end;
+  GameStats counted;                           // game counters summed over the measured batches
+  long advance_batches = 0, past_opening_at_start = 0;
 };
 
 }  // namespace p3
@@ -624,6 +627,7 @@ long g_last_bias_pruned = 0;
 double g_last_bias_adj = 0;
 int g_num_groups = 2;
 long g_step_limit = 0;   // > 0: the measured region ends after this many engine batches
+int g_advance_limit = 0;   // > 0: untimed batches per group, at most, to play every game past its raw-policy opening
 long g_last_reuse_added = 0, g_last_examples = 0;
 }
 
@@ -652,14 +656,18 @@ void p3host_selfplay_set_early_stopping(int enabled) { g_early_stopping = enable
 // bias-cache entries pruned / sum of |root adjustment| over the moves of the last run or game
 long p3host_selfplay_last_bias_pruned() { return g_last_bias_pruned; }
 double p3host_selfplay_last_bias_adj() { return g_last_bias_adj; }
-// Number of game groups of subsequent p3host_selfplay_run calls (>= 2).  Each group has its own
+// Number of game groups of subsequent p3host_selfplay_run calls (1..8).  Each group has its own
 // engine instance and is either being advanced on the host or evaluated on the GPU; with G
-// groups up to G - 1 forward passes are in flight while one group is on the host.
-void p3host_selfplay_set_groups(int n) { g_num_groups = n < 2 ? 2 : (n > 8 ? 8 : n); }
-// > 0: subsequent p3host_selfplay_run calls measure exactly ceil(batches / groups) rounds of one
-// engine batch per group (bench.py's --steps) instead of running for `seconds`; 0 restores the
-// time limit.
+// groups up to G - 1 forward passes are in flight while one group is on the host (one group:
+// host and GPU alternate, BASELINE configs[2] as written).
+void p3host_selfplay_set_groups(int n) { g_num_groups = n < 1 ? 1 : (n > 8 ? 8 : n); }
+// > 0: subsequent p3host_selfplay_run calls measure exactly `batches` engine batches (bench.py's
+// --steps), whichever groups they fall in, instead of running for `seconds`; 0 restores the time limit.
 void p3host_selfplay_set_step_limit(long batches) { g_step_limit = batches > 0 ? batches : 0; }
+// > 0: before the warm-up batches every group runs untimed batches until all its games have left
+// their raw-policy opening (up to 30 moves of one evaluation each, self_play_thread.cc:44,363-366),
+// at most `max_batches` of them, so that a short measured region is steady-state search; 0 = off.
+void p3host_selfplay_set_advance_limit(int max_batches) { g_advance_limit = max_batches > 0 ? max_batches : 0; }
 // reuse-buffer insertions and training examples written by the last p3host_selfplay_run
 long p3host_selfplay_last_reuse_added() { return g_last_reuse_added; }
 long p3host_selfplay_last_examples() { return g_last_examples; }
@@ -697,6 +705,8 @@ struct p3host_selfplay_stats {
   double gpu_seconds;        // time spent inside Evaluator::Run, summed over both halves
   double host_seconds;       // time spent advancing games (both halves, wall)
   long cache_hits;           // evaluations served by the per-game cache (not in `positions`)
+  long advance_batches;      // untimed batches of the advance phase, all groups (p3host_selfplay_set_advance_limit)
+  long games_past_opening;   // games past their raw-policy opening when the measured region began
 };
 
 // Runs self-play for about `seconds` (after `warmup_batches` unmeasured batches per half).
@@ -777,49 +787,74 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     return t;
   };
 
-  // Every group runs on its own: warm-up batches, then its share of the measured batches (or the
-  // measured time), then unmeasured batches until every group has finished measuring, so the GPU
-  // sees the same load for the whole of every group's measured region.  A batch = advance all
-  // games of the group to their next leaf (host pool), then one engine run.
-  const long batch_limit = g_step_limit > 0 ? (g_step_limit + NG - 1) / NG : 0;   // per group
-  std::atomic<int> groups_done{0};
+  // Every group runs on its own: advance batches (until its games are past their openings), warm-up
+  // batches, then measured batches.  A batch = advance all games of the group to their next leaf
+  // (host pool), then one engine run.  The measured region is one window for the whole job: it opens
+  // when the last group finishes its warm-up (at that run's completion) and closes at the completion
+  // of the `g_step_limit`-th run after that (or the first completion `seconds` later), whichever
+  // groups those runs fall in; every run that completes inside the window is counted, with the game
+  // counters of the host advance that loaded it.  The groups keep the GPU under the same load for the
+  // whole window: a group leaves only when it sees the window closed.
+  const bool by_steps = g_step_limit > 0;
+  const long step_limit = g_step_limit;
+  const int advance_limit = g_advance_limit;
+  std::mutex clock_mu;
+  int phase = 0, groups_ready = 0;   // 0 advance + warm-up, 1 measuring, 2 over (guarded by clock_mu)
+  long counted = 0;
+  std::chrono::steady_clock::time_point t0{}, t1{};
   std::atomic<bool> failed{false};
   for (int h = 0; h < NG; ++h) {
     halves[h].driver = std::thread([&, h] {
       Half& H = halves[h];
       advance_half(h, false);
-      long batches = 0;
-      bool measuring = false, done = false;
+      long warm = 0;
+      bool ready = false;
+      int adv_left = advance_limit;
+      double last_host = 0;
+      GameStats prev = group_totals(H);
       for (;;) {
         const auto r0 = std::chrono::steady_clock::now();
         const bool ok = H.eval->Run();
         const auto r1 = std::chrono::steady_clock::now();
-        ++batches;
         // here the group's games are quiescent (results not yet delivered): counters can be read
         if (!ok) { H.ok = false; failed.store(true); }
-        if (measuring && !done) {
-          ++H.measured_batches;
-          H.gpu_seconds += std::chrono::duration<double>(r1 - r0).count();
-          const bool enough = batch_limit > 0 ? H.measured_batches >= batch_limit
-                                              : std::chrono::duration<double>(r1 - H.t_start).count() >= seconds;
-          if (enough || failed.load()) {
-            H.t_end = r1;
-            H.end = group_totals(H);
-            done = true;
-            groups_done.fetch_add(1);
+        const GameStats now = group_totals(H);
+        bool over = false;
+        {
+          std::lock_guard<std::mutex> l(clock_mu);
+          if (phase == 1) {
+            ++H.measured_batches;
+            ++counted;
+            H.counted.moves += now.moves - prev.moves; H.counted.games += now.games - prev.games;
+            H.counted.evals += now.evals - prev.evals; H.counted.black_wins += now.black_wins - prev.black_wins;
+            H.counted.cache_hits += now.cache_hits - prev.cache_hits;
+            H.counted.bias_entries_pruned += now.bias_entries_pruned - prev.bias_entries_pruned;
+            H.counted.bias_adj_abs_sum += now.bias_adj_abs_sum - prev.bias_adj_abs_sum;
+            H.gpu_seconds += std::chrono::duration<double>(r1 - r0).count();
+            H.host_seconds += last_host;
+            const bool enough = by_steps ? counted >= step_limit : std::chrono::duration<double>(r1 - t0).count() >= seconds;
+            if (enough || failed.load()) { phase = 2; t1 = r1; }
+          } else if (phase == 0 && !ready) {
+            bool in_opening = false;
+            if (adv_left > 0) {
+              for (auto& g : H.games)
+                if (!g->past_opening()) { in_opening = true; break; }
+            }
+            if (in_opening) { --adv_left; ++H.advance_batches; }
+            else { adv_left = 0; ++warm; }
+            if (warm >= warmup_batches || failed.load()) {
+              ready = true;
+              for (auto& g : H.games) H.past_opening_at_start += g->past_opening();
+              if (++groups_ready == NG) { phase = failed.load() ? 2 : 1; t0 = t1 = r1; }
+            }
           }
+          over = phase == 2;
         }
-        if (!measuring && (batches >= warmup_batches || failed.load())) {
-          // the measured region starts here: its first batch is loaded by the advance below
-          H.base = group_totals(H);
-          H.t_start = r1;
-          measuring = true;
-          if (failed.load()) { H.t_end = r1; H.end = H.base; done = true; groups_done.fetch_add(1); }
-        }
-        if (done && groups_done.load() >= NG) break;
+        if (over) break;
+        prev = now;
         const auto a0 = std::chrono::steady_clock::now();
         advance_half(h, true);
-        if (measuring && !done) H.host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
+        last_host = std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
       }
     });
   }
@@ -837,25 +872,79 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     std::memset(out, 0, sizeof *out);
     g_last_bias_pruned = 0;
     g_last_bias_adj = 0;
-    // the job's clock: from the first group that started measuring to the last that finished
-    auto t0 = halves[0].t_start, t1 = halves[0].t_end;
     for (auto& H : halves) {
-      if (H.t_start < t0) t0 = H.t_start;
-      if (H.t_end > t1) t1 = H.t_end;
-      out->positions += H.end.evals - H.base.evals;
-      out->moves += H.end.moves - H.base.moves;
-      out->games += H.end.games - H.base.games;
-      out->black_wins += H.end.black_wins - H.base.black_wins;
-      out->cache_hits += H.end.cache_hits - H.base.cache_hits;
+      out->positions += H.counted.evals;
+      out->moves += H.counted.moves;
+      out->games += H.counted.games;
+      out->black_wins += H.counted.black_wins;
+      out->cache_hits += H.counted.cache_hits;
       out->batches += H.measured_batches;
       out->gpu_seconds += H.gpu_seconds;
       out->host_seconds += H.host_seconds;
-      g_last_bias_pruned += H.end.bias_entries_pruned - H.base.bias_entries_pruned;
-      g_last_bias_adj += H.end.bias_adj_abs_sum - H.base.bias_adj_abs_sum;
+      out->advance_batches += H.advance_batches;
+      out->games_past_opening += H.past_opening_at_start;
+      g_last_bias_pruned += H.counted.bias_entries_pruned;
+      g_last_bias_adj += H.counted.bias_adj_abs_sum;
     }
     out->seconds = std::chrono::duration<double>(t1 - t0).count();
   }
   return rc;
+}
+
+// The reference's engine micro-benchmark, nn::Benchmark (cc/nn/engine/benchmark_engine.cc:77-108), over
+// any library exporting the C ABI: 100 warm-up RunInference calls, then at most 1001 rounds (the
+// reference's `num_inferences > 1000` bound) of LoadBatch x B -> RunInference -> GetBatch x B on ONE
+// thread, the clock around RunInference only (its `elapsed_us`); `loop_seconds` is the whole timed loop,
+// loads and gets included.  The reference walks a dataset that is not in its repository; here the
+// rounds cycle through `n_feats` caller-supplied positions.  One difference, by design of the engine:
+// this engine evaluates loaded slots only (the TRT engine always runs its static batch), so the batch is
+// loaded once before the warm-up runs and they do the same work as the timed ones.
+struct p3host_engine_benchmark_stats {
+  long rounds, positions;
+  double avg_run_us;        // mean of the per-round RunInference time (DefaultStats "avg_us")
+  double loop_seconds;      // wall time of the timed loop: loads + runs + gets
+  double checksum;          // sum over every fetched result of move_probs[argmax] (keeps the gets honest)
+};
+int p3host_engine_benchmark(const char* engine_lib, const char* weights, int device, int batch,
+                            const p3hip_features* feats, int n_feats, int warmup_runs, int max_rounds,
+                            p3host_engine_benchmark_stats* out, char* err) {
+  if (!engine_lib || !engine_lib[0] || !feats || n_feats <= 0 || batch <= 0) {
+    if (err) snprintf(err, 256, "engine_benchmark: engine library, positions and batch size are required");
+    return 1;
+  }
+  HipEvaluator e;
+  if (!e.Open(engine_lib, weights, batch, device)) {
+    if (err) snprintf(err, 256, "%s", e.err.c_str());
+    return 1;
+  }
+  for (int b = 0; b < batch; ++b) e.Load(b, feats[b % n_feats]);
+  for (int i = 0; i < warmup_runs; ++i)
+    if (!e.Run()) { if (err) snprintf(err, 256, "%s", e.err.c_str()); return 2; }
+  p3hip_result r;
+  double run_us = 0, checksum = 0;
+  long rounds = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (; rounds < max_rounds; ++rounds) {
+    const long off = rounds * (long)batch;
+    for (int b = 0; b < batch; ++b) e.Load(b, feats[(off + b) % n_feats]);
+    const auto s = std::chrono::steady_clock::now();
+    if (!e.Run()) { if (err) snprintf(err, 256, "%s", e.err.c_str()); return 2; }
+    run_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s).count();
+    for (int b = 0; b < batch; ++b) {
+      e.Get(b, r);
+      float best = r.move_probs[0];
+      for (int i = 1; i < kNumMoves; ++i) best = std::max(best, r.move_probs[i]);
+      checksum += best;
+    }
+  }
+  if (out) {
+    out->rounds = rounds;
+    out->positions = rounds * (long)batch;
+    out->avg_run_us = rounds ? run_us / rounds : 0;
+    out->loop_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    out->checksum = checksum;
+  }
+  return 0;
 }
 
 // Plays ONE game to the end with the NullEvaluator or the HIP engine on a single thread and
@@ -1060,6 +1149,9 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
   std::vector<int> want(num_games, 0), base(num_games, 0), need(num_games, 0);
   std::vector<std::vector<int>> slot_of(num_games);          // evaluation i of game g -> engine slot offset, -1 = cached
   std::vector<std::vector<EvalCache::Key>> key_of(num_games);
+  // copies of the cached results found in advance(): the deliveries below interleave with Insert(),
+  // which may evict the very entry a later evaluation of the same round hit (cache smaller than a round)
+  std::vector<std::vector<p3hip_result>> hit_of(num_games);
   std::vector<p3hip_features> feats(2 * (size_t)slots);
   long positions = 0, batches = 0;
   std::atomic<long> cache_hits{0};
@@ -1074,12 +1166,14 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
       EvalCache& cache = caches[2 * g + e];
       slot_of[g].assign(want[g], -1);
       key_of[g].resize(want[g]);
+      if ((int)hit_of[g].size() < want[g]) hit_of[g].resize(want[g]);
       for (int i = 0; i < want[g]; ++i) {
         key_of[g][i] = cache.MakeKey(games[g]->eval_position(i), games[g]->eval_color_of(i));
-        if (!cache.Find(key_of[g][i])) slot_of[g][i] = need[g]++;
+        if (const p3hip_result* hit = cache.Find(key_of[g][i])) hit_of[g][i] = *hit;
+        else slot_of[g][i] = need[g]++;
       }
       if (need[g] > 0) return;
-      for (int i = 0; i < want[g]; ++i) games[g]->DeliverCached(i, *cache.Find(key_of[g][i]));   // all cached
+      for (int i = 0; i < want[g]; ++i) games[g]->DeliverCached(i, hit_of[g][i]);   // all cached
       cache_hits.fetch_add(want[g], std::memory_order_relaxed);
     }
   };
@@ -1133,7 +1227,7 @@ int p3host_eval_match(const char* engine_lib, const char* cur_weights, const cha
       p3hip_result r;
       for (int i = 0; i < want[g]; ++i) {
         if (slot_of[g][i] < 0) {
-          games[g]->DeliverCached(i, *cache.Find(key_of[g][i]));
+          games[g]->DeliverCached(i, hit_of[g][i]);
           cache_hits.fetch_add(1, std::memory_order_relaxed);
           continue;
         }

@@ -129,7 +129,8 @@ class Board:
 class SelfPlayStats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("positions", C.c_long), ("moves", C.c_long),
                 ("games", C.c_long), ("black_wins", C.c_long), ("batches", C.c_long),
-                ("gpu_seconds", C.c_double), ("host_seconds", C.c_double), ("cache_hits", C.c_long)]
+                ("gpu_seconds", C.c_double), ("host_seconds", C.c_double), ("cache_hits", C.c_long),
+                ("advance_batches", C.c_long), ("games_past_opening", C.c_long)]
 
 
 def selfplay_run(weights: str | None, num_games: int, num_threads: int, seconds: float,
@@ -152,6 +153,30 @@ def selfplay_run(weights: str | None, num_games: int, num_threads: int, seconds:
                                warmup_batches, seed, C.byref(st), err)
     if rc != 0:
         raise RuntimeError(f"selfplay_run rc={rc}: {err.value.decode()}")
+    return st
+
+
+class EngineBenchmarkStats(C.Structure):
+    _fields_ = [("rounds", C.c_long), ("positions", C.c_long), ("avg_run_us", C.c_double),
+                ("loop_seconds", C.c_double), ("checksum", C.c_double)]
+
+
+def engine_benchmark(weights: str, positions: np.ndarray, batch: int, warmup_runs: int = 100, max_rounds: int = 1001,
+                     device: int = 0, engine_lib: str | None = None) -> EngineBenchmarkStats:
+    """nn::Benchmark (cc/nn/engine/benchmark_engine.cc:77-108) in C++ over the C ABI: 100 warm-up runs, then
+    <= 1001 rounds of LoadBatch x B -> RunInference -> GetBatch x B, timed around RunInference.
+    `positions`: array of p3hip_features records (features.FEATURES_DTYPE)."""
+    L = lib()
+    L.p3host_engine_benchmark.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_int, C.POINTER(EngineBenchmarkStats), C.c_char_p]
+    st = EngineBenchmarkStats()
+    err = C.create_string_buffer(256)
+    pos = np.ascontiguousarray(positions)
+    elib = (engine_lib or os.path.join(_HERE, "csrc", "libp3hip.so")).encode()
+    rc = L.p3host_engine_benchmark(elib, weights.encode(), device, batch, pos.ctypes.data, len(pos), warmup_runs,
+                                   max_rounds, C.byref(st), err)
+    if rc != 0:
+        raise RuntimeError(f"engine_benchmark rc={rc}: {err.value.decode()}")
     return st
 
 
@@ -239,9 +264,18 @@ def set_groups(n: int) -> None:
     L.p3host_selfplay_set_groups(n)
 
 
+def set_advance_limit(max_batches: int) -> None:
+    """> 0: before the warm-up every group of subsequent selfplay_run calls runs untimed batches, at most
+    this many, until all its games have left their raw-policy opening (self_play_thread.cc:44,363-366);
+    0 = off (the default)."""
+    L = lib()
+    L.p3host_selfplay_set_advance_limit.argtypes = [C.c_int]
+    L.p3host_selfplay_set_advance_limit(int(max_batches))
+
+
 def set_step_limit(batches: int) -> None:
-    """> 0: subsequent selfplay_run calls time exactly ceil(batches / groups) rounds of one engine
-    batch per game group (bench.py --steps) instead of running for `seconds`; 0 = time limit."""
+    """> 0: subsequent selfplay_run calls time exactly `batches` engine batches (bench.py --steps),
+    whichever game groups they fall in, instead of running for `seconds`; 0 = time limit."""
     L = lib()
     L.p3host_selfplay_set_step_limit.argtypes = [C.c_long]
     L.p3host_selfplay_set_step_limit(int(batches))

@@ -411,6 +411,25 @@ def test_eval_match_cache_sgf_and_result_file(built, tmp_path):
     assert float(res.read_text()) == pytest.approx(st.rel_elo, abs=1e-4) or not np.isfinite(st.rel_elo)
 
 
+@pytest.mark.parametrize("cap", [1, 2])
+def test_eval_match_with_a_cache_smaller_than_a_round(built, cap):
+    """--cache_size below the evaluations of one round (leaves_per_round = 8): a round's hits are copied
+    out when they are found, because the deliveries of the same round insert into the cache and may evict
+    the entry a later evaluation hit (the round-2 advisor's case: cap 1, miss then hit).  Same searches as
+    without a cache, every hit one engine slot less."""
+    try:
+        host_api.eval_set_search(cache_entries_per_game=0)
+        st0 = host_api.eval_match(None, None, num_games=6, visits_per_move=24, leaves_per_round=8, max_moves=30,
+                                  num_threads=2, seed=11)
+        host_api.eval_set_search(cache_entries_per_game=cap)
+        st = host_api.eval_match(None, None, num_games=6, visits_per_move=24, leaves_per_round=8, max_moves=30,
+                                 num_threads=2, seed=11)
+    finally:
+        host_api.eval_set_search()
+    assert st.games == 6 and st.moves == st0.moves == 6 * 30
+    assert st.positions + st.cache_hits == st0.positions and st.visits == st0.visits
+
+
 @pytest.mark.parametrize("mcgs,descent,bias", [(True, 0, 0.0), (False, 1, 0.0), (True, 1, 0.3)])
 def test_eval_match_graph_search_buuct_and_bias_cache(built, mcgs, descent, bias):
     """use_mcgs (McgsNodeTable, node_table.h:77-118), descent_policy bu_uct (search.h:174-251) and

@@ -471,6 +471,38 @@ def test_selfplay_host_over_the_cpu_engine_and_step_limit(built, weight_files):
     assert st.seconds > 0
 
 
+def test_advance_phase_plays_every_game_past_its_opening_before_the_timed_steps(built):
+    """bench.py's untimed advance phase: a game samples its first moves from the raw policy,
+    one evaluation per move, for up to 30 moves (self_play_thread.cc:44,363-366); with the advance limit set every
+    group runs untimed batches until all its games are past that, so a SHORT timed window is Gumbel search
+    (n = 16 here: close to 16 evaluations per move, not 1) and it holds exactly the requested number of
+    batches, whichever groups they fall in (5 is not a multiple of the 3 groups)."""
+    from p3achygo_amd import host_api
+    host_api.set_groups(3)
+    host_api.set_step_limit(5)
+    try:
+        host_api.set_advance_limit(0)
+        cold = host_api.selfplay_run(None, num_games=96, num_threads=4, seconds=0.0, default_n=16, default_k=4,
+                                     selected_n=16, selected_k=4, warmup_batches=1, seed=12)
+        host_api.set_advance_limit(64)
+        warm = host_api.selfplay_run(None, num_games=96, num_threads=4, seconds=0.0, default_n=16, default_k=4,
+                                     selected_n=16, selected_k=4, warmup_batches=1, seed=12)
+        host_api.set_groups(1)           # BASELINE configs[2] as written: one group, host and engine alternate
+        solo = host_api.selfplay_run(None, num_games=32, num_threads=4, seconds=0.0, default_n=16, default_k=4,
+                                     selected_n=16, selected_k=4, warmup_batches=1, seed=12)
+    finally:
+        host_api.set_step_limit(0)
+        host_api.set_advance_limit(0)
+        host_api.set_groups(2)
+    assert cold.batches == warm.batches == solo.batches == 5
+    assert cold.positions == warm.positions == 5 * 32 and solo.positions == 5 * 32
+    assert cold.advance_batches == 0 and cold.games_past_opening < 96      # most games still in their openings
+    assert cold.moves > 0.5 * cold.positions                               # ~1 evaluation per move there
+    assert 0 < warm.advance_batches <= 3 * 64 and warm.games_past_opening == 96
+    assert warm.moves * 8 < warm.positions                                 # search: many evaluations per move
+    assert solo.games_past_opening == 32
+
+
 def test_baseline_config_c1_plumbing_on_the_cpu_engine(built, weight_files):
     """BASELINE configs[0]: "v4-b8 random-init net, 1 self-play thread, n=8 k=4 Gumbel, TF-CPU inference
     (plumbing, no GPU)".  v4 = b8c128nbt with bias_cache_lambda 0.3 / alpha 0.8 (config/v4.json); the

@@ -72,3 +72,32 @@ def test_cpu_placement_rules():
     assert s.cpus_for_rank(range(4), 5, 8) == [0, 1, 2, 3]
     assert s._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
     assert s.gpu_numa_node("ffff:ff:1f.0") is None
+
+
+def test_bench_gpus_flag_starts_that_many_ranks(built):
+    """`python bench.py --gpus 2` — the driver's invocation shape when no launcher set WORLD_SIZE — starts two
+    rank processes itself (python/rl_loop/sp_loop.py:160-192 starts one self-play process per GPU) and rank 0
+    prints one JSON line with n_gpus 2; a WORLD_SIZE that disagrees with --gpus is refused.  Run over the host's
+    NullEvaluator (--null-engine: no GPU here), which the line says."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--null-engine", "--steps", "7", "--warmup", "2",
+           "--batch", "16", "--groups", "3"]
+    one = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run(cmd + ["--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                        # rank 0 alone prints
+    b = json.loads(lines[0])
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2
+    assert a["steps"] == b["steps"] == 7                          # exactly --steps, not rounded to whole rounds
+    assert a["engine_batches_completed"] == 7 and b["engine_batches_completed"] == 14   # K per rank, summed
+    assert b["positions"] == 2 * a["positions"] == 2 * 7 * 16     # weak scaling: per-rank work fixed
+    assert b["games_past_opening"] == b["games_total"] == 2 * 3 * 16
+    assert "NOT a measurement" in b["engine"] and b["roofline"] is None
+    bad = subprocess.run(cmd + ["--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True,
+                         text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr

@@ -298,6 +298,11 @@ __device__ __forceinline__ void epi_params16(EpiParams16& ep, const float* __res
     ep.sc[ct] = *(const f32x4*)(scale + c0 + 16 * ct);
     ep.sh[ct] = *(const f32x4*)(shift + c0 + 16 * ct);
   }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {   // times log2(e): bn_mish4_l2 / bn_mish8_l2
+    ep.sc[ct] = scale_log2e(ep.sc[ct]);
+    ep.sh[ct] = scale_log2e(ep.sh[ct]);
+  }
 }
 
 template <int NTn>
@@ -307,12 +312,21 @@ struct EpiOut16 { h4 o[NTn][4]; };
 template <int NTn>
 __device__ __forceinline__ void epilogue_math16(EpiOut16<NTn>& eo, f32x4 (&acc)[4][NTn],
                                                 const EpiParams16& ep) {
+#ifdef P3_EPI_CHAINS   // A/B: one dependent chain per pair of values
 #pragma unroll
   for (int j = 0; j < NTn; ++j) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) eo.o[j][ct] = bn_mish4(acc[ct][j], ep.sc[ct], ep.sh[ct]);
+    for (int ct = 0; ct < 4; ++ct) eo.o[j][ct] = bn_mish4_l2(acc[ct][j], ep.sc[ct], ep.sh[ct]);
     __builtin_amdgcn_sched_barrier(0);   // one tile at a time: bounds the live temporaries
   }
+#else
+#pragma unroll
+  for (int j = 0; j < NTn; ++j) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ct += 2)   // eight values in flight per stage
+      bn_mish8_l2(acc[ct][j], acc[ct + 1][j], ep.sc[ct], ep.sh[ct], ep.sc[ct + 1], ep.sh[ct + 1], eo.o[j][ct], eo.o[j][ct + 1]);
+  }
+#endif
 }
 
 __device__ __forceinline__ void half_swap(h4& x, h4& y);   // defined with the HBM epilogues below
@@ -472,13 +486,13 @@ __device__ __forceinline__ void activate_loaded16(EpiOut16<NTn>& A, const ResReg
   const int c0 = cofs + cg_of<G, COUT_PASS>() * 64 + q * 4;
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
-    const f32x4 sc = *(const f32x4*)(scale + c0 + 16 * ct), sh = *(const f32x4*)(shift + c0 + 16 * ct);
+    const f32x4 sc = scale_log2e(*(const f32x4*)(scale + c0 + 16 * ct)), sh = scale_log2e(*(const f32x4*)(shift + c0 + 16 * ct));
 #pragma unroll
     for (int b = 0; b < NTn / 2; ++b) {
       h4 r0, r1;
       residual_unpack16<NTn>(xin, b, ct, r0, r1);
-      A.o[2 * b][ct] = bn_mish4(f32x4{(float)r0[0], (float)r0[1], (float)r0[2], (float)r0[3]}, sc, sh);
-      A.o[2 * b + 1][ct] = bn_mish4(f32x4{(float)r1[0], (float)r1[1], (float)r1[2], (float)r1[3]}, sc, sh);
+      bn_mish8_l2(f32x4{(float)r0[0], (float)r0[1], (float)r0[2], (float)r0[3]}, f32x4{(float)r1[0], (float)r1[1], (float)r1[2], (float)r1[3]},
+                  sc, sh, sc, sh, A.o[2 * b][ct], A.o[2 * b + 1][ct]);
     }
     __builtin_amdgcn_sched_barrier(0);   // one cout tile at a time: bounds the live temporaries
   }
@@ -506,13 +520,13 @@ __device__ __forceinline__ void activate_stashed16(EpiOut16<NTn>& A, const float
   const int c0 = cofs + cg_of<G, COUT_PASS>() * 64 + q * 4;
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
-    const f32x4 sc = *(const f32x4*)(scale + c0 + 16 * ct), sh = *(const f32x4*)(shift + c0 + 16 * ct);
+    const f32x4 sc = scale_log2e(*(const f32x4*)(scale + c0 + 16 * ct)), sh = scale_log2e(*(const f32x4*)(shift + c0 + 16 * ct));
 #pragma unroll
     for (int b = 0; b < NTn / 2; ++b) {
       h4 r0 = A.o[2 * b][ct], r1 = A.o[2 * b + 1][ct];
       half_swap(r0, r1);
-      A.o[2 * b][ct] = bn_mish4(f32x4{(float)r0[0], (float)r0[1], (float)r0[2], (float)r0[3]}, sc, sh);
-      A.o[2 * b + 1][ct] = bn_mish4(f32x4{(float)r1[0], (float)r1[1], (float)r1[2], (float)r1[3]}, sc, sh);
+      bn_mish8_l2(f32x4{(float)r0[0], (float)r0[1], (float)r0[2], (float)r0[3]}, f32x4{(float)r1[0], (float)r1[1], (float)r1[2], (float)r1[3]},
+                  sc, sh, sc, sh, A.o[2 * b][ct], A.o[2 * b + 1][ct]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -559,6 +573,7 @@ __device__ __forceinline__ void epilogue_store16_act(f32x4 (&acc)[4][NTn], const
       sc = *(const f32x4*)(scale + c0 + 16 * ct);
       sh = *(const f32x4*)(shift + c0 + 16 * ct);
     }
+    const f32x4 scl = scale_log2e(sc), shl = scale_log2e(sh);   // bn_mish8_l2 takes them times log2(e)
 #pragma unroll
     for (int b = 0; b < NTn / 2; ++b) {
       h4 r0, r1;
@@ -570,8 +585,8 @@ __device__ __forceinline__ void epilogue_store16_act(f32x4 (&acc)[4][NTn], const
         o1[i] = (_Float16)(acc[ct][2 * b + 1][i] + (float)r1[i]);
       }
       if (act) {
-        A.o[2 * b][ct] = bn_mish4(f32x4{(float)o0[0], (float)o0[1], (float)o0[2], (float)o0[3]}, sc, sh);
-        A.o[2 * b + 1][ct] = bn_mish4(f32x4{(float)o1[0], (float)o1[1], (float)o1[2], (float)o1[3]}, sc, sh);
+        bn_mish8_l2(f32x4{(float)o0[0], (float)o0[1], (float)o0[2], (float)o0[3]}, f32x4{(float)o1[0], (float)o1[1], (float)o1[2], (float)o1[3]},
+                    scl, shl, scl, shl, A.o[2 * b][ct], A.o[2 * b + 1][ct]);
       } else {   // defined on every path, or the previous block's A stays live through this one
         A.o[2 * b][ct] = h4{0, 0, 0, 0};
         A.o[2 * b + 1][ct] = h4{0, 0, 0, 0};

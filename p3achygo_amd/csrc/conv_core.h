@@ -114,10 +114,51 @@ __device__ __forceinline__ f32x2 mish_f2(f32x2 x) {
   const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
   return __builtin_elementwise_fma(x * -2.0f, r, x);
 }
-__device__ __forceinline__ h4 bn_mish4(f32x4 v, f32x4 sc, f32x4 sh) {
-  const f32x2 a = mish_f2(__builtin_elementwise_fma(f32x2{v[0], v[1]}, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]}));
-  const f32x2 b = mish_f2(__builtin_elementwise_fma(f32x2{v[2], v[3]}, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]}));
+
+// The hot epilogues take their BN parameters pre-multiplied by log2(e) (scale_log2e below, once per epilogue):
+//   t = log2(e) * (sc * v + sh) = log2(e) * y,   e = 2^t = e^y,
+//   mish(y) = y * (1 - 2 / ((e + 1)^2 + 1)) = t * (ln2 - 2 ln2 / (e * (e + 2) + 2)).
+// Per pair of values: fma, exp2 x2, add, fma, rcp x2, fma, mul — five packed operations instead of six.
+// e -> inf: d = inf, r = 0, result t * ln2 = y; e -> 0: r = 1/2, the last fma gives exactly 0.
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+__device__ __forceinline__ f32x4 scale_log2e(f32x4 v) { return v * kLog2e; }
+__device__ __forceinline__ f32x2 mish_t2(f32x2 t) {
+  const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  const f32x2 d = __builtin_elementwise_fma(e, e + 2.0f, f32x2{2.0f, 2.0f});
+  const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  return t * __builtin_elementwise_fma(r, f32x2{-2.0f * kLn2, -2.0f * kLn2}, f32x2{kLn2, kLn2});
+}
+// scl, shl: folded BN scale / shift times log2(e)
+__device__ __forceinline__ h4 bn_mish4_l2(f32x4 v, f32x4 scl, f32x4 shl) {
+  const f32x2 a = mish_t2(__builtin_elementwise_fma(f32x2{v[0], v[1]}, f32x2{scl[0], scl[1]}, f32x2{shl[0], shl[1]}));
+  const f32x2 b = mish_t2(__builtin_elementwise_fma(f32x2{v[2], v[3]}, f32x2{scl[2], scl[3]}, f32x2{shl[2], shl[3]}));
   return h4{(_Float16)a[0], (_Float16)a[1], (_Float16)b[0], (_Float16)b[1]};
+}
+// The same arithmetic on EIGHT values stage by stage (4 packed operations or 8 transcendentals per stage, the
+// stages pinned in this order): bn_mish4_l2 is one dependent chain per pair of values; eight independent values keep
+// the VALU's issue slots filled (a wave with its SIMD's VALU to itself runs the chains at their latency).
+// Bit-identical to bn_mish4_l2.
+__device__ __forceinline__ void bn_mish8_l2(f32x4 v0, f32x4 v1, f32x4 sc0, f32x4 sh0, f32x4 sc1, f32x4 sh1, h4& o0, h4& o1) {
+  f32x2 t[4], w[4];
+  t[0] = __builtin_elementwise_fma(f32x2{v0[0], v0[1]}, f32x2{sc0[0], sc0[1]}, f32x2{sh0[0], sh0[1]});
+  t[1] = __builtin_elementwise_fma(f32x2{v0[2], v0[3]}, f32x2{sc0[2], sc0[3]}, f32x2{sh0[2], sh0[3]});
+  t[2] = __builtin_elementwise_fma(f32x2{v1[0], v1[1]}, f32x2{sc1[0], sc1[1]}, f32x2{sh1[0], sh1[1]});
+  t[3] = __builtin_elementwise_fma(f32x2{v1[2], v1[3]}, f32x2{sc1[2], sc1[3]}, f32x2{sh1[2], sh1[3]});
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = f32x2{__builtin_amdgcn_exp2f(t[k][0]), __builtin_amdgcn_exp2f(t[k][1])};
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = __builtin_elementwise_fma(w[k], w[k] + 2.0f, f32x2{2.0f, 2.0f});
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = f32x2{__builtin_amdgcn_rcpf(w[k][0]), __builtin_amdgcn_rcpf(w[k][1])};
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t[k] = t[k] * __builtin_elementwise_fma(w[k], f32x2{-2.0f * kLn2, -2.0f * kLn2}, f32x2{kLn2, kLn2});
+  __builtin_amdgcn_sched_barrier(0);
+  o0 = h4{(_Float16)t[0][0], (_Float16)t[0][1], (_Float16)t[1][0], (_Float16)t[1][1]};
+  o1 = h4{(_Float16)t[2][0], (_Float16)t[2][1], (_Float16)t[3][0], (_Float16)t[3][1]};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -483,6 +524,11 @@ __device__ __forceinline__ void epi_params(EpiParams& ep, const float* __restric
     ep.sc[k] = *(const f32x4*)(scale + c0 + 8 * k);
     ep.sh[k] = *(const f32x4*)(shift + c0 + 8 * k);
   }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {  // times log2(e): bn_mish8_l2
+    ep.sc[k] = scale_log2e(ep.sc[k]);
+    ep.sh[k] = scale_log2e(ep.sh[k]);
+  }
 }
 
 // The epilogue is split at the barrier: epilogue_math (BN + mish + fp16 pack, registers
@@ -497,10 +543,11 @@ __device__ __forceinline__ void epilogue_math(EpiOut<NTn>& eo, f32x16 (&acc)[2][
 #pragma unroll
   for (int j = 0; j < NTn; ++j)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 8; k += 2) {   // eight values in flight per stage
       const int mt = k >> 2, g4 = k & 3;
-      const f32x4 v = {acc[mt][j][g4 * 4], acc[mt][j][g4 * 4 + 1], acc[mt][j][g4 * 4 + 2], acc[mt][j][g4 * 4 + 3]};
-      eo.o[j][k] = bn_mish4(v, ep.sc[k], ep.sh[k]);
+      const f32x4 v0 = {acc[mt][j][g4 * 4], acc[mt][j][g4 * 4 + 1], acc[mt][j][g4 * 4 + 2], acc[mt][j][g4 * 4 + 3]};
+      const f32x4 v1 = {acc[mt][j][g4 * 4 + 4], acc[mt][j][g4 * 4 + 5], acc[mt][j][g4 * 4 + 6], acc[mt][j][g4 * 4 + 7]};
+      bn_mish8_l2(v0, v1, ep.sc[k], ep.sh[k], ep.sc[k + 1], ep.sh[k + 1], eo.o[j][k], eo.o[j][k + 1]);
     }
 }
 
@@ -588,8 +635,8 @@ __device__ __forceinline__ void stage_store(char* smem, const XRegs<G>& xr, int 
   f32x4 s0, s1, t0, t1;
   if (PRE) {
     const int c = (cblk0 + kc) * 8;
-    s0 = *(const f32x4*)(scale + c); s1 = *(const f32x4*)(scale + c + 4);
-    t0 = *(const f32x4*)(shift + c); t1 = *(const f32x4*)(shift + c + 4);
+    s0 = scale_log2e(*(const f32x4*)(scale + c)); s1 = scale_log2e(*(const f32x4*)(scale + c + 4));
+    t0 = scale_log2e(*(const f32x4*)(shift + c)); t1 = scale_log2e(*(const f32x4*)(shift + c + 4));
   }
 #pragma unroll
   for (int i = 0; i < kXLoads; ++i) {
@@ -598,8 +645,9 @@ __device__ __forceinline__ void stage_store(char* smem, const XRegs<G>& xr, int 
     const h8 v = xr.v[i];
     h8 o;
     if (PRE) {
-      const h4 lo = bn_mish4(f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, s0, t0);
-      const h4 hi = bn_mish4(f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]}, s1, t1);
+      h4 lo, hi;
+      bn_mish8_l2(f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]},
+                  s0, t0, s1, t1, lo, hi);
       o = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     } else {
       o = v;
@@ -620,13 +668,14 @@ __device__ __forceinline__ void stage_math(XRegs<G>& xr, int cblk0, const float*
   const int combo = launder(threadIdx.x) >> 5;
   const int kc = combo % G::NCH;
   const int c = (cblk0 + kc) * 8;
-  const f32x4 s0 = *(const f32x4*)(scale + c), s1 = *(const f32x4*)(scale + c + 4);
-  const f32x4 t0 = *(const f32x4*)(shift + c), t1 = *(const f32x4*)(shift + c + 4);
+  const f32x4 s0 = scale_log2e(*(const f32x4*)(scale + c)), s1 = scale_log2e(*(const f32x4*)(scale + c + 4));
+  const f32x4 t0 = scale_log2e(*(const f32x4*)(shift + c)), t1 = scale_log2e(*(const f32x4*)(shift + c + 4));
 #pragma unroll
   for (int i = 0; i < kXLoads; ++i) {
     const h8 v = xr.v[i];
-    const h4 lo = bn_mish4(f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, s0, t0);
-    const h4 hi = bn_mish4(f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]}, s1, t1);
+    h4 lo, hi;
+    bn_mish8_l2(f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]},
+                s0, t0, s1, t1, lo, hi);
     xr.v[i] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   }
 }

@@ -759,14 +759,14 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
 #pragma unroll
           for (int gp = 0; gp < 2; ++gp) {
             h4 o[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              const int g4 = 2 * gp + k;
+            {
+              const int g4 = 2 * gp;
               const int c = half * CH + ct * 32 + g4 * 8 + h * 4;
-              const f32x4 sc = *(const f32x4*)(p_scale + c);
-              const f32x4 sh = *(const f32x4*)(p_shift + c);
-              const f32x4 v = {acc[mt][g4 * 4] + bj, acc[mt][g4 * 4 + 1] + bj, acc[mt][g4 * 4 + 2] + bj, acc[mt][g4 * 4 + 3] + bj};
-              o[k] = bn_mish4(v, sc, sh);
+              const f32x4 sc0 = scale_log2e(*(const f32x4*)(p_scale + c)), sh0 = scale_log2e(*(const f32x4*)(p_shift + c));
+              const f32x4 sc1 = scale_log2e(*(const f32x4*)(p_scale + c + 8)), sh1 = scale_log2e(*(const f32x4*)(p_shift + c + 8));
+              const f32x4 v0 = {acc[mt][g4 * 4] + bj, acc[mt][g4 * 4 + 1] + bj, acc[mt][g4 * 4 + 2] + bj, acc[mt][g4 * 4 + 3] + bj};
+              const f32x4 v1 = {acc[mt][g4 * 4 + 4] + bj, acc[mt][g4 * 4 + 5] + bj, acc[mt][g4 * 4 + 6] + bj, acc[mt][g4 * 4 + 7] + bj};
+              bn_mish8_l2(v0, v1, sc0, sh0, sc1, sh1, o[0], o[1]);
             }
             half_swap32(o[0], o[1]);
             const h8 piece = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};

@@ -203,10 +203,16 @@ __device__ __forceinline__ void ring_issue(Ring<RS, NW, D>& r, char* smem) {
   const uint32_t lane16 = (threadIdx.x & 63) * 16;
   const char* gp = r.gcur + lane16;      // uniform base + 32-bit lane offset
   char* lp = smem + r.fill[0];
+  // (P3_PROBE_*: timing probes, garbage results: the kernel without its weight ring's LDS-DMA runs 19 % faster,
+  // without the ring's barriers 7 %, without both 22.5 %; every re-arrangement of the DMA tried in round 3 — issued
+  // by one wave per SIMD for both, spread over the macro-step instead of right behind the barrier — measured
+  // slower than this one: profiles/r03_ring_probes.txt)
+#ifndef P3_PROBE_NO_RING_DMA
 #pragma unroll
   for (int i = 0; i < Ring<RS, NW, D>::G; ++i)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + i * 1024),
                                      (__attribute__((address_space(3))) void*)(lp + i * 1024), 16, 0, 0);
+#endif
   r.gcur += RS;
   if (r.gcur == r.gend) r.gcur = r.gbeg;
   rotate_left(r.fill);
@@ -261,7 +267,9 @@ __device__ __forceinline__ uint32_t ring_acquire(Ring<RS, NW, D>& r, char* smem)
   } else {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"(B), "n"(LGKM) : "memory");
   }
+#ifndef P3_PROBE_NO_RING_BARRIER
   __builtin_amdgcn_s_barrier();
+#endif
   asm volatile("" ::: "memory");
   ring_issue(r, smem);
   const uint32_t off = r.use[0];

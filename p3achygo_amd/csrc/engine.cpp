@@ -826,7 +826,23 @@ int p3hip_cache_enable(p3hip_engine* e, int log2_entries) {
             e->check(hipHostMalloc((void**)&c.h_lists, 5 * B * 4, hipHostMallocDefault), "hipHostMalloc") &&
             e->check(hipHostMalloc((void**)&c.h_sym, B * 4, hipHostMallocDefault), "hipHostMalloc") &&
             e->check(hipMemset(c.d_tkeys, 0, cap * 16), "hipMemset") && e->check(hipMemset(c.d_tmeta, 0, cap * 4), "hipMemset");
-  if (!ok) return 1;
+  if (!ok) {
+    // free what was allocated (an over-large table fails at the records): a later, smaller enable starts clean
+    const std::string why = e->err;
+    hipFree(c.d_tkeys); hipFree(c.d_tmeta); hipFree(c.d_tvals); hipFree(c.d_keys); hipFree(c.d_hit); hipFree(c.d_victim);
+    hipFree(c.d_lists); hipFree(c.d_sym); hipFree(c.d_feats2);
+    if (c.h_keys) hipHostFree(c.h_keys);
+    if (c.h_hit) hipHostFree(c.h_hit);
+    if (c.h_victim) hipHostFree(c.h_victim);
+    if (c.h_lists) hipHostFree(c.h_lists);
+    if (c.h_sym) hipHostFree(c.h_sym);
+    c.d_tkeys = nullptr; c.d_tmeta = nullptr; c.d_tvals = nullptr; c.d_keys = nullptr; c.d_hit = nullptr; c.d_victim = nullptr;
+    c.d_lists = nullptr; c.d_sym = nullptr; c.d_feats2 = nullptr;
+    c.h_keys = nullptr; c.h_hit = nullptr; c.h_victim = nullptr; c.h_lists = nullptr; c.h_sym = nullptr;
+    (void)hipGetLastError();   // the failed allocation's sticky error
+    e->err = why;
+    return 1;
+  }
   c.h_slot_keys = new p3::CacheKey[B]();
   c.out_row.assign(B, -1);
   c.was_hit.assign(B, 0);

@@ -137,10 +137,11 @@ class NNInterface final {
   void SetNumCacheLastMoves(int n) { num_cache_last_moves_ = n; }   // [0, 5], default 5
   Evaluator* engine() { return engine_.get(); }
 
-  // The cache moves from this object's per-thread LRUs into the engine's HBM table (p3hip_cache_*): one table
-  // for every worker and game, looked up and filled by the run itself.  Same contract towards the search — a
-  // position seen before returns the result stored then, un-rotated — except that a hit still takes part in a
-  // run (it costs a table probe, not a forward pass).  False when the engine has no such table.
+  // Adds the engine's HBM table (p3hip_cache_*) behind this object's per-thread LRUs: one table for every worker
+  // and game, looked up and filled by the run itself.  A position a thread has seen itself comes from its own LRU
+  // at once, as in the reference (nn_interface.cc:112-118: no slot, no run); one that only another thread or game
+  // has seen takes part in a run and costs a table probe instead of a forward pass.  Same contract towards the
+  // search either way: the result stored at the first evaluation, un-rotated.  False when the engine has no table.
   bool EnableDeviceCache(int log2_entries) {
     device_cache_ = engine_->EnableDeviceCache(log2_entries);
     return device_cache_;
@@ -151,21 +152,16 @@ class NNInterface final {
 
   // Blocks until the result is ready (nn_interface.cc:108-133).
   p3hip_result LoadAndGetInference(int thread_id, const Game& game, Color color_to_move, Probability& prob) {
-    if (device_cache_) {
-      const Symmetry sym = RandomSymmetry(prob.prng());
-      LoadBatchKeyed(thread_id, game, color_to_move, sym);
-      SignalLoadedAndBlockUntilReady(thread_id);
-      return GetBatchKeyed(thread_id, sym);
-    }
     const Key key = MakeKey(game, color_to_move);
     if (caches_[thread_id].Contains(key)) {
       MarkCached(thread_id, true);
       return *caches_[thread_id].Get(key);
     }
     const Symmetry sym = RandomSymmetry(prob.prng());
-    LoadBatch(thread_id, game, color_to_move, sym);
+    if (device_cache_) LoadBatchKeyed(thread_id, game, color_to_move, sym);
+    else LoadBatch(thread_id, game, color_to_move, sym);
     SignalLoadedAndBlockUntilReady(thread_id);
-    p3hip_result r = GetBatch(thread_id, sym);
+    p3hip_result r = device_cache_ ? GetBatchKeyed(thread_id, sym) : GetBatch(thread_id, sym);
     caches_[thread_id].Insert(key, r);
     return r;
   }
@@ -207,20 +203,6 @@ class NNInterface final {
   // async API (nn_interface.cc:172-230)
   void LoadEntry(int thread_id, int offset, const Game& game, Color color_to_move, Probability& prob) {
     const int tid = thread_id + offset;
-    if (device_cache_) {
-      const Symmetry sym = RandomSymmetry(prob.prng());
-      syms_[tid] = sym;
-      LoadBatchKeyed(tid, game, color_to_move, sym);
-      {
-        std::lock_guard<std::mutex> l(mu_);
-        ThreadInfo& t = info_[tid];
-        t.loaded = true;
-        t.res_ready.store(false, std::memory_order_relaxed);
-        t.res_cached = false;
-      }
-      infer_cv_.notify_all();
-      return;
-    }
     const Key key = MakeKey(game, color_to_move);
     if (caches_[tid].Contains(key)) {
       MarkCached(tid, true);
@@ -228,7 +210,8 @@ class NNInterface final {
     }
     const Symmetry sym = RandomSymmetry(prob.prng());
     syms_[tid] = sym;
-    LoadBatch(tid, game, color_to_move, sym);
+    if (device_cache_) LoadBatchKeyed(tid, game, color_to_move, sym);
+    else LoadBatch(tid, game, color_to_move, sym);
     {
       std::lock_guard<std::mutex> l(mu_);
       ThreadInfo& t = info_[tid];
@@ -240,17 +223,13 @@ class NNInterface final {
   }
   p3hip_result FetchEntry(int thread_id, int offset, const Game& game, Color color_to_move) {
     const int tid = thread_id + offset;
-    if (device_cache_) {
-      Wait(tid);
-      return GetBatchKeyed(tid, syms_[tid]);
-    }
     const Key key = MakeKey(game, color_to_move);
     if (caches_[tid].Contains(key)) {
       MarkCached(tid, false);
       return *caches_[tid].Get(key);
     }
     Wait(tid);
-    p3hip_result r = GetBatch(tid, syms_[tid]);
+    p3hip_result r = device_cache_ ? GetBatchKeyed(tid, syms_[tid]) : GetBatch(tid, syms_[tid]);
     caches_[tid].Insert(key, r);
     return r;
   }

@@ -209,9 +209,11 @@ extern "C" {
 // positions through LoadAndGetInference (a fresh random symmetry per call) and, every other round, through the
 // async LoadEntry / FetchEntry pair.  Every result, un-rotated by the interface, must show the game's own
 // stones.  out: {mismatching results, engine evaluations, engine hits, interface-counted hits, distinct keys}.
-int p3host_test_nn_device_cache(int positions, int rounds, uint64_t seed, long out[5]) {
+// host_cache_entries: the interface's own LRU in front of the table (0: every repeat reaches the engine's table;
+// large: a thread's own repeats are answered at once, without a slot or a run, as in the reference).
+int p3host_test_nn_device_cache(int positions, int rounds, uint64_t seed, int host_cache_entries, long out[5]) {
   auto* ev = new KeyedTableEvaluator(4);
-  NNInterface nn(1, NNInterface::kTimeoutUs, 1 << 10, std::unique_ptr<Evaluator>(ev));
+  NNInterface nn(1, NNInterface::kTimeoutUs, (size_t)host_cache_entries, std::unique_ptr<Evaluator>(ev));
   if (!nn.EnableDeviceCache(10) || !nn.device_cache()) return 1;
   Probability prob(seed);
   std::vector<Game> games;

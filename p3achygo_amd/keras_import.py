@@ -84,7 +84,12 @@ def convert(datasets: Dict[str, np.ndarray], cfg: netspec.NetConfig) -> Tuple[Di
     for label, rows in (("Keras 3 object paths", keras_map.object_path_map(cfg)), ("layer-name paths", keras_map.name_map(cfg))):
         missing = [k for k, _ in rows if k not in ds]
         if missing:
-            tried.append(f"{label}: {len(missing)} of {len(rows)} absent, e.g. {missing[0]}")
+            # name the dataset paths closest to the first absent keys: a real checkpoint whose groups are
+            # named differently from this map (it has met no file the reference saved) shows here how
+            import difflib
+            spare = sorted(set(ds) - {k for k, _ in rows})
+            near = "; ".join(f"{k} ~ {difflib.get_close_matches(k, spare, n=2, cutoff=0.3) or 'nothing alike'}" for k in missing[:4])
+            tried.append(f"{label}: {len(missing)} of {len(rows)} absent (nearest unmatched dataset paths: {near})")
             continue
         out: Dict[str, np.ndarray] = {}
         for k, name in rows:

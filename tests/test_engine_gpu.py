@@ -591,3 +591,74 @@ def test_device_nn_cache_serves_hits_bit_identical_and_evaluates_only_misses(bui
             assert sym == int(p) % 8 and np.array_equal(raw, want[p])
     assert 0 < hits < 12 * 32 and small.cache_stats()["hits"] == hits
     small.close()
+
+
+def test_device_nn_cache_of_an_impossible_size_fails_cleanly(built, weight_files):
+    """p3hip_cache_enable with a table larger than the GPU's memory (2^26 entries x 13.7 KB = 917 GB of the 288)
+    returns an error and keeps nothing of what it had allocated before the records failed; a smaller table can
+    then be enabled on the same engine and serves hits (round-2 advisor: the failed call used to leave its buffers
+    behind and the second call leaked them)."""
+    from p3achygo_amd import engine, features
+    path = weight_files("test_b3c128btl2", randomize=True)
+    pos = features.random_positions(8, seed=5, n_games=4)
+    eng = engine.HipEngine(path, 8)
+    with pytest.raises(engine.EngineError):
+        eng.EnableCache(26)
+    eng.EnableCache(10)
+    for rnd in range(2):
+        for i in range(8):
+            eng.LoadBatchKeyed(i, pos[i:i + 1], 1000 + i, 7, symmetry=0)
+        eng.RunInference()
+        outs = [np.ctypeslib.as_array(eng.GetBatchKeyed(i)[0].move_logits).copy() for i in range(8)]
+        if rnd == 0:
+            first = outs
+    assert all(np.array_equal(a, b) for a, b in zip(first, outs))
+    st = eng.cache_stats()
+    assert st["hits"] >= 8 and st["entries"] == 1 << 10     # the second round was served from the table
+    eng.close()
+
+
+def test_baseline_config_c5_eval_match_with_the_hbm_cache_on_the_full_size_nets(built, weight_files):
+    """BASELINE configs[4] as a configuration: "v3-b10c384nbt / b14c384 large trunk, fp16, NN-eval cache on (cc/eval
+    path)" — the reference's thread-per-game match (eval/main.cc:380-452) between the two FULL-DEPTH C = 384 nets with
+    the NN cache in the engines' HBM tables behind the interfaces' LRUs.  Few games, few visits (a full-size forward
+    pass of a handful of positions is latency-bound: this is a correctness test, the rate is tools/gpu_eval_threads_cache.py's).
+      (i)  what the engines serve with the cache on is the nets' output: the golden positions of each net, loaded
+           keyed into an engine with a table, first evaluation against the float64 fixture within the tolerances above;
+      (ii) a hit is the first evaluation bit for bit (asked again under another symmetry and from other slots);
+      (iii) the match itself completes through the keyed path, every game with a result, and lookups reach the tables."""
+    from p3achygo_amd import engine, host_api
+    nets = ("b10c384nbt", "b14c384btl3")
+    for name in nets:
+        g, pos = load_golden(name)
+        eng = engine.create_engine(engine.Kind.kHip, weight_files(name), 8, 1)
+        eng.EnableCache(12)
+        n = len(pos)
+        for i in range(n):
+            eng.LoadBatchKeyed(i, pos[i:i + 1], 0x1000 + i, 0xabc, symmetry=i % 8)
+        eng.RunInference()
+        first = []
+        for i in range(n):
+            res, sym, hit = eng.GetBatchKeyed(i)
+            assert not hit and sym == i % 8
+            _check(eng.get_raw(i), res, g["raw"][i], {k: g[k][i] for k in PROB_KEYS})
+            first.append(np.ctypeslib.as_array(res.move_logits).copy())
+        for i in range(n):                                   # again: other slots, another symmetry asked for
+            eng.LoadBatchKeyed(n + i, pos[i:i + 1], 0x1000 + i, 0xabc, symmetry=(i + 3) % 8)
+        eng.RunInference()
+        for i in range(n):
+            res, sym, hit = eng.GetBatchKeyed(n + i)
+            assert hit and sym == i % 8                      # the stored record, under the symmetry it was stored with
+            assert np.array_equal(np.ctypeslib.as_array(res.move_logits), first[i])
+        st = eng.cache_stats()
+        assert st["hits"] == n and st["stored"] == n
+        eng.close()
+    host_api.set_device_nn_cache(12)
+    try:
+        st = host_api.eval_match_threads(weight_files(nets[0]), weight_files(nets[1]), num_games=4, visits_per_move=8,
+                                         threads_per_game=3, max_moves=6, cache_size=1 << 12, seed=11)
+    finally:
+        host_api.set_device_nn_cache(0)
+    assert st.games == 4 and st.cur_wins + st.cand_wins + st.draws == 4 and st.moves >= 4
+    lookups, hits = host_api.device_nn_cache_lookups(), host_api.device_nn_cache_hits()
+    assert lookups >= st.moves and 0 <= hits < lookups

@@ -91,6 +91,10 @@ def test_keras_import_refuses_what_does_not_fit():
     assert cfg.name == "tiny"
     with pytest.raises(KeyError, match="does not hold the tensors of b8c128nbt"):
         keras_import.convert(ds, netspec.CONFIGS["b8c128nbt"])
+    # a checkpoint whose groups are named differently from the map: the message shows the nearest dataset paths
+    renamed = {k.replace("init_board_conv", "init_board_conv2d"): v for k, v in ds.items()}
+    with pytest.raises(KeyError, match="nearest unmatched dataset paths: .*init_board_conv2d"):
+        keras_import.convert(renamed, cfg)
     bad = dict(ds)
     first = keras_map.object_path_map(cfg)[0][0]
     bad[first] = bad[first][..., :-1]

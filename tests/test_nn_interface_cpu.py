@@ -179,7 +179,7 @@ def test_thread_per_game_driver_with_unregistering_threads(L):
 
 
 def test_nn_interface_over_an_engine_side_cache_unrotates_by_the_stored_symmetry():
-    """NNInterface with the cache in the engine (EnableDeviceCache; include/p3hip.h p3hip_cache_*) instead of its
+    """NNInterface with the cache in the engine (EnableDeviceCache; include/p3hip.h p3hip_cache_*) behind its
     per-thread LRUs (cc/nn/nn_interface.cc:107-132).  A fake engine with the HIP engine's cache rules returns, on a
     hit, the result it stored under the symmetry of THAT evaluation; every call draws a fresh random symmetry, so a
     hit whose result were un-rotated by the caller's own symmetry would show rotated stones.  200 positions x 6
@@ -189,9 +189,14 @@ def test_nn_interface_over_an_engine_side_cache_unrotates_by_the_stored_symmetry
     from p3achygo_amd import host_api
     L = host_api.lib()
     out = (C.c_long * 5)()
-    L.p3host_test_nn_device_cache.argtypes = [C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_long)]
-    assert L.p3host_test_nn_device_cache(200, 6, 12345, out) == 0
+    L.p3host_test_nn_device_cache.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_long)]
+    assert L.p3host_test_nn_device_cache(200, 6, 12345, 0, out) == 0       # no host LRU: every repeat reaches the table
     bad, evaluated, hits, counted, keys = list(out)
     assert bad == 0
     assert evaluated == keys and 150 <= keys <= 200          # random playouts may repeat a position
     assert hits == counted == 200 * 6 - evaluated
+    # with the interface's own LRU in front (the reference's order, nn_interface.cc:112-118): a thread's own
+    # repeats are answered at once and never reach the engine; only first sightings are evaluated
+    assert L.p3host_test_nn_device_cache(200, 6, 12345, 1 << 10, out) == 0
+    bad, evaluated, hits, counted, keys = list(out)
+    assert bad == 0 and evaluated == keys and hits == counted == 0

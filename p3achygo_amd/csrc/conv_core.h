@@ -203,10 +203,11 @@ __device__ __forceinline__ void ring_issue(Ring<RS, NW, D>& r, char* smem) {
   const uint32_t lane16 = (threadIdx.x & 63) * 16;
   const char* gp = r.gcur + lane16;      // uniform base + 32-bit lane offset
   char* lp = smem + r.fill[0];
-  // (P3_PROBE_*: timing probes, garbage results: the kernel without its weight ring's LDS-DMA runs 19 % faster,
-  // without the ring's barriers 7 %, without both 22.5 %; every re-arrangement of the DMA tried in round 3 — issued
-  // by one wave per SIMD for both, spread over the macro-step instead of right behind the barrier — measured
-  // slower than this one: profiles/r03_ring_probes.txt)
+  // (P3_PROBE_*: timing probes, garbage results.  Without the ring's barriers k_block needs 5 % fewer cycles; without
+  // its LDS-DMA 2 % fewer — and 15-19 % less wall time, but only because the ring then holds no weights and the chip
+  // clocks 14 % higher on the lighter MFMA operands, not because of the DMA: profiles/r03_sq_pmc_ring_probes.txt.
+  // Every re-arrangement of the DMA tried in round 3 — issued by one wave per SIMD for both, spread over the
+  // macro-step instead of right behind the barrier — measured slower than this one: profiles/r03_ring_probes.txt)
 #ifndef P3_PROBE_NO_RING_DMA
 #pragma unroll
   for (int i = 0; i < Ring<RS, NW, D>::G; ++i)

@@ -282,6 +282,7 @@ def main():
     host_api.set_advance_limit(0)
     ladder1 = host_api.ladder_stats()
     dt = sharding.max_over_ranks(shard, st.seconds)
+    dt_fit = sharding.max_over_ranks(shard, st.seconds_fit)
     sharding.barrier(shard)
     totals = sharding.sum_over_ranks(shard, [st.positions, st.moves, st.games, st.batches, st.cache_hits,
                                              ladder1[0] - ladder0[0], ladder1[3] - ladder0[3],
@@ -312,6 +313,9 @@ def main():
             "engine_batches_completed": totals[3], "mean_batch_fill": totals[0] / max(steps * n_gpus, 1) / args.batch,
             "eval_cache_hits": totals[4], "ladder_readouts": totals[5], "ladder_budget_hits": totals[6],
             "seconds_timed": dt, "wall_s_incl_setup_advance_and_warmup": wall,
+            # the same K steps, per-step time from a least-squares line through all K + 1 completion instants instead of
+            # the first and the last (completions come in bursts: a 20-step window's end points are +-1 batch = +-5 %)
+            "value_fit": totals[0] / dt_fit, "seconds_timed_fit": dt_fit,
         }
 
     if not use_gpu:

@@ -707,6 +707,10 @@ struct p3host_selfplay_stats {
   long cache_hits;           // evaluations served by the per-game cache (not in `positions`)
   long advance_batches;      // untimed batches of the advance phase, all groups (p3host_selfplay_set_advance_limit)
   long games_past_opening;   // games past their raw-policy opening when the measured region began
+  // batches x the least-squares slope of (batch index, completion instant) over the window: the same K steps, but
+  // every completion weighs in instead of the first and the last (the groups' kernels interleave on the GPU, so
+  // completions come in bursts and a short window's end points are +-1 batch); `seconds` is the window itself
+  double seconds_fit;
 };
 
 // Runs self-play for about `seconds` (after `warmup_batches` unmeasured batches per half).
@@ -802,6 +806,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   int phase = 0, groups_ready = 0;   // 0 advance + warm-up, 1 measuring, 2 over (guarded by clock_mu)
   long counted = 0;
   std::chrono::steady_clock::time_point t0{}, t1{};
+  std::vector<double> done_at;   // completion instants of the counted batches, seconds since t0 (guarded by clock_mu)
   std::atomic<bool> failed{false};
   for (int h = 0; h < NG; ++h) {
     halves[h].driver = std::thread([&, h] {
@@ -825,6 +830,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
           if (phase == 1) {
             ++H.measured_batches;
             ++counted;
+            done_at.push_back(std::chrono::duration<double>(r1 - t0).count());
             H.counted.moves += now.moves - prev.moves; H.counted.games += now.games - prev.games;
             H.counted.evals += now.evals - prev.evals; H.counted.black_wins += now.black_wins - prev.black_wins;
             H.counted.cache_hits += now.cache_hits - prev.cache_hits;
@@ -887,6 +893,20 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
       g_last_bias_adj += H.counted.bias_adj_abs_sum;
     }
     out->seconds = std::chrono::duration<double>(t1 - t0).count();
+    out->seconds_fit = out->seconds;
+    {
+      // completion k (1-based) at done_at[k - 1], the window's opening = completion 0 at 0
+      const size_t n = done_at.size() + 1;
+      if (n >= 4) {
+        double sx = 0, sy = 0, sxx = 0, sxy = 0;
+        for (size_t k = 0; k < n; ++k) {
+          const double x = (double)k, y = k == 0 ? 0.0 : done_at[k - 1];
+          sx += x; sy += y; sxx += x * x; sxy += x * y;
+        }
+        const double slope = (n * sxy - sx * sy) / (n * sxx - sx * sx);
+        if (slope > 0) out->seconds_fit = slope * (double)(n - 1);
+      }
+    }
   }
   return rc;
 }

@@ -130,7 +130,7 @@ class SelfPlayStats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("positions", C.c_long), ("moves", C.c_long),
                 ("games", C.c_long), ("black_wins", C.c_long), ("batches", C.c_long),
                 ("gpu_seconds", C.c_double), ("host_seconds", C.c_double), ("cache_hits", C.c_long),
-                ("advance_batches", C.c_long), ("games_past_opening", C.c_long)]
+                ("advance_batches", C.c_long), ("games_past_opening", C.c_long), ("seconds_fit", C.c_double)]
 
 
 def selfplay_run(weights: str | None, num_games: int, num_threads: int, seconds: float,

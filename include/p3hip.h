@@ -98,6 +98,9 @@ typedef struct p3hip_engine p3hip_engine;
 #define P3HIP_FLAG_SHARED_DEVICE 4u /* several engines keep this GPU busy at once (the self-play host's game groups, the
                                        two players of a match): launches leave out the start-up stagger that only pays
                                        when a launch has the GPU to itself */
+#define P3HIP_FLAG_LAUNCH_GRAPH 8u  /* a run over the full static batch replays ONE captured launch graph, as
+                                       TrtEngineImpl::RunInference does (trt_engine.cc:260-303); runs over fewer slots
+                                       (compaction, cache hits) are launched kernel by kernel.  Same kernels, same results */
 
 /* Creates an engine from a `.p3w` weight file (see p3achygo_amd/netspec.py) for a static
  * batch of `batch_size` slots on HIP device `device_ordinal`.  `version` is the model
@@ -171,6 +174,9 @@ int p3hip_get_raw(p3hip_engine* e, int slot, float* out);
  * unpadded 361 points). */
 double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
                                double* flops_per_launch, const char** kernel_name);
+/* P3HIP_FLAG_LAUNCH_GRAPH: 1 once the full-batch forward pass has been captured and is being replayed,
+ * 0 before (or without the flag), -1 when the capture failed and the engine fell back to plain launches. */
+int p3hip_graph_state(const p3hip_engine* e);
 /* Algorithmic FLOPs (2*MAC) of one position: total, and 3x3 trunk convs only. */
 void p3hip_flops_per_position(const p3hip_engine* e, double* total, double* conv3x3);
 

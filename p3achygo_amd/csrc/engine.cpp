@@ -210,6 +210,10 @@ struct p3hip_engine {
   bool bcast_fuse = true;  // P3HIP_NO_BFUSE clears it: broadcast 1x1 convs as their own launches (A/B, tests)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // P3HIP_FLAG_LAUNCH_GRAPH: the forward pass over the full static batch, captured once (trt_engine.cc:260-303)
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  bool graph_failed = false, graph_warm = false;
   // p3hip_time_trunk_kernel: event pairs around every fused-block launch of a forward pass
   std::vector<hipEvent_t> blk_ev;
   bool time_blocks = false;
@@ -693,11 +697,44 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
   return true;
 }
 
+// The forward pass of a run: one captured graph for the full static batch when the engine was created with
+// P3HIP_FLAG_LAUNCH_GRAPH (the reference's TensorRT engine replays a captured graph, trt_engine.cc:260-303), the
+// kernel-by-kernel launches otherwise and for every other position count.  The first full-batch run goes out
+// kernel by kernel (the launchers set their kernels' LDS attributes on first use, which a capture must not see),
+// the second is captured, the rest replay.  A capture that fails falls back to the launches for good.
+bool run_forward(p3hip_engine* e, int npos) {
+  const bool want = (e->flags & P3HIP_FLAG_LAUNCH_GRAPH) && npos == e->batch && !e->time_blocks && !e->graph_failed;
+  if (!want) return enqueue_forward(e, npos);
+  if (e->graph_exec) return e->check(hipGraphLaunch(e->graph_exec, e->stream), "hipGraphLaunch");
+  if (!e->graph_warm) {
+    e->graph_warm = true;
+    return enqueue_forward(e, npos);
+  }
+  if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    e->graph_failed = true;
+    (void)hipGetLastError();
+    return enqueue_forward(e, npos);
+  }
+  const bool ok = enqueue_forward(e, npos);
+  hipGraph_t g = nullptr;
+  const hipError_t ce = hipStreamEndCapture(e->stream, &g);
+  if (!ok || ce != hipSuccess || !g || hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
+    if (g) hipGraphDestroy(g);
+    e->graph_exec = nullptr;
+    e->graph_failed = true;
+    (void)hipGetLastError();
+    return enqueue_forward(e, npos);   // nothing was executed by the capture
+  }
+  e->graph = g;
+  return e->check(hipGraphLaunch(e->graph_exec, e->stream), "hipGraphLaunch");
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* p3hip_create_error(void) { return g_create_error.c_str(); }
+int p3hip_graph_state(const p3hip_engine* e) { return e->graph_failed ? -1 : (e->graph_exec ? 1 : 0); }
 
 p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version,
                            int device_ordinal, uint32_t flags) {
@@ -779,6 +816,8 @@ void p3hip_destroy(p3hip_engine* e) {
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   for (hipEvent_t ev : e->blk_ev) hipEventDestroy(ev);
+  if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
+  if (e->graph) hipGraphDestroy(e->graph);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
 }
@@ -885,7 +924,7 @@ int p3hip_upload(p3hip_engine* e) {
 
 int p3hip_forward_resident(p3hip_engine* e, int n_positions) {
   if (n_positions < 1 || n_positions > e->batch || !e->bind()) return 1;
-  return enqueue_forward(e, n_positions) ? 0 : 1;
+  return run_forward(e, n_positions) ? 0 : 1;
 }
 
 int p3hip_sync(p3hip_engine* e) { return e->bind() && e->check(hipStreamSynchronize(e->stream), "sync") ? 0 : 1; }
@@ -944,7 +983,7 @@ static int run_cached(p3hip_engine* e, int n) {
     if (!e->check(p3::launch_cache_gather(a, s), "launch k_cache_gather")) return 1;
     unsigned char* keep = e->d_feats;
     e->d_feats = c.d_feats2;
-    const bool ok = enqueue_forward(e, nm);
+    const bool ok = run_forward(e, nm);
     e->d_feats = keep;
     if (!ok) return 1;
   }
@@ -970,7 +1009,7 @@ int p3hip_run(p3hip_engine* e) {
   if (e->cache.on) return run_cached(e, n);
   if (!e->check(hipMemcpyAsync(e->d_feats, e->h_feats_compact, (size_t)n * kFeatBytes,
                                hipMemcpyHostToDevice, e->stream), "H2D features")) return 1;
-  if (!enqueue_forward(e, n)) return 1;
+  if (!run_forward(e, n)) return 1;
   if (!e->check(hipMemcpy2DAsync(e->h_out, p3::kResultFloats * 4, e->d_out, p3::kOutStride * 4,
                                  p3::kResultFloats * 4, n, hipMemcpyDeviceToHost, e->stream), "D2H results")) return 1;
   return e->check(hipStreamSynchronize(e->stream), "sync") ? 0 : 1;

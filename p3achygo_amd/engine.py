@@ -27,12 +27,13 @@ EXPORTS = [
     "p3hip_create", "p3hip_create_error", "p3hip_destroy", "p3hip_kind", "p3hip_path",
     "p3hip_batch_size", "p3hip_load_slot", "p3hip_run", "p3hip_get_slot", "p3hip_get_ownership",
     "p3hip_last_error", "p3hip_forward_resident", "p3hip_upload", "p3hip_sync", "p3hip_get_raw",
-    "p3hip_time_trunk_kernel", "p3hip_flops_per_position",
+    "p3hip_time_trunk_kernel", "p3hip_flops_per_position", "p3hip_graph_state",
     "p3hip_cache_enable", "p3hip_load_slot_keyed", "p3hip_get_slot_keyed", "p3hip_cache_stats",
 ]
 
 FLAG_RUN_ALL_SLOTS = 2
 FLAG_SHARED_DEVICE = 4
+FLAG_LAUNCH_GRAPH = 8
 
 
 class EngineError(RuntimeError):
@@ -203,6 +204,11 @@ class HipEngine:
         if ms < 0:
             raise EngineError("time_trunk_kernel: " + self._L.p3hip_last_error(self._h).decode())
         return ms, fl.value, (name.value or b"").decode()
+
+    def graph_state(self) -> int:
+        """P3HIP_FLAG_LAUNCH_GRAPH: 1 replaying the captured forward pass, 0 not (yet), -1 capture failed."""
+        self._L.p3hip_graph_state.argtypes = [C.c_void_p]
+        return int(self._L.p3hip_graph_state(self._h))
 
     def flops_per_position(self):
         t, c = C.c_double(0), C.c_double(0)

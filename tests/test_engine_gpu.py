@@ -662,3 +662,34 @@ def test_baseline_config_c5_eval_match_with_the_hbm_cache_on_the_full_size_nets(
     assert st.games == 4 and st.cur_wins + st.cand_wins + st.draws == 4 and st.moves >= 4
     lookups, hits = host_api.device_nn_cache_lookups(), host_api.device_nn_cache_hits()
     assert lookups >= st.moves and 0 <= hits < lookups
+
+
+def test_launch_graph_replays_the_full_batch_forward_bit_for_bit(built, weight_files):
+    """P3HIP_FLAG_LAUNCH_GRAPH: a run over the full static batch replays one captured launch graph, as the
+    reference's TensorRT engine does (trt_engine.cc:260-303: capture once, cudaGraphLaunch per RunInference); the
+    first such run goes out kernel by kernel, the second is captured, later ones replay.  Same kernels: every run is
+    bit-identical to an engine without the flag, runs over fewer slots in between (launched kernel by kernel) too."""
+    from p3achygo_amd import engine, features
+    path = weight_files("test_b3c256btl1", randomize=True)
+    B = 64
+    pos = features.random_positions(B, seed=21, n_games=16)
+    ref = engine.HipEngine(path, B)
+    gr = engine.HipEngine(path, B, flags=engine.FLAG_LAUNCH_GRAPH)
+
+    def run(eng, idx):
+        for i in idx:
+            eng.LoadBatch(i, pos[i:i + 1])
+        eng.RunInference()
+        return [eng.get_raw(i).copy() for i in idx]
+
+    full = list(range(B))
+    want = run(ref, full)
+    for rnd in range(5):                       # eager, capture, replay, replay, replay
+        got = run(gr, full)
+        assert all(np.array_equal(a, b) for a, b in zip(want, got)), rnd
+        assert gr.graph_state() == (1 if rnd >= 1 else 0) and ref.graph_state() == 0
+        if rnd == 2:                           # a ragged run between replays
+            part = [3, 17, 40]
+            assert all(np.array_equal(a, b) for a, b in zip(run(ref, part), run(gr, part)))
+    ref.close()
+    gr.close()

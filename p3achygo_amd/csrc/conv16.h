@@ -78,7 +78,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Addressing: one VGPR per 32-row tile pair (at kernel row ky, leftmost tap);
 // kernel column kx, the odd 16-row tile and the k32 index inside the tap are immediates.
 // Body = one kernel row (KW taps), runtime loop over ky.
-template <class G, int COUT_PASS, int KW, int NTAPS_PAD, int NTn = 0>
+// SWAP: mfma(act fragment, weight fragment), i.e. the tile transposed — lane (n, q) of tile (ct, j) then holds
+//   D: acc[ct][j][i] = out[cout = ct*16 + n][row = row0(j) + 2*(4q + i)]
+// four board rows of ONE channel (epilogue_tt16: the channel-major image the broadcast dense contracts over).
+template <class G, int COUT_PASS, int KW, int NTAPS_PAD, bool SWAP = false, int NTn = 0>
 __device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS, G::KMS), G::NW, G::RD>& ring, char* smem,
                                                f32x4 (&acc)[4][NTn]) {
   using T = Tiling16<G, COUT_PASS>;
@@ -155,7 +158,8 @@ __device__ __forceinline__ void conv_segment16(Ring<ring_slot_bytes(COUT_PASS, G
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-          acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[u % 2][ct], fb[j], acc[ct][j], 0, 0, 0);
+          acc[ct][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[u % 2][ct], acc[ct][j], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[u % 2][ct], fb[j], acc[ct][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (do_fetch) fetch_piece(o, std::integral_constant<int, u + 1>{}, J);
         __builtin_amdgcn_sched_barrier(0);
@@ -620,6 +624,34 @@ __device__ __forceinline__ void epilogue_store16_mish(f32x4 (&acc)[4][NTn], cons
       half_swap(o0, o1);   // every lane takes part
       const h8 piece = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
       if (rr.ok[b]) *(h8*)(oc + (uint32_t)(rr.base[b] * 2u)) = piece;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The same conv_first, taken with SWAP accumulators, when the broadcast dense follows in the same launch:
+// t = mish(acc) -> fp16 -> Tt[channel of this pass][padded board row], TT_STRIDE bytes per channel (k_bdense's LDS
+// image, K = the 384 padded rows of the act buffer instead of 361 board points + 23 zeros; the dense matrix is
+// packed to match, engine.cpp).  A lane's two tiles of a pair interleave to 8 consecutive rows: one 16-byte store.
+// Rows off the board come out as mish(0) = 0: the act buffer's halo slots are zero and the conv is 1x1.
+template <class G, int COUT_PASS, int TT_STRIDE, int NTn>
+__device__ __forceinline__ void epilogue_tt16(char* smem, f32x4 (&acc)[4][NTn]) {
+  using T = Tiling16<G, COUT_PASS>;
+  static_assert(G::NPOS == 1 && G::NT_TOTAL == T::LG * (NTn / 2), "one position, every tile pair real");
+  const int lane = launder(threadIdx.x & 63);
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = wid % T::CG, lg = wid / T::CG;
+  const int n = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+    for (int b = 0; b < NTn / 2; ++b) {
+      const f32x2 a0 = mish_f2(f32x2{acc[ct][2 * b][0], acc[ct][2 * b][1]}), a1 = mish_f2(f32x2{acc[ct][2 * b][2], acc[ct][2 * b][3]});
+      const f32x2 b0 = mish_f2(f32x2{acc[ct][2 * b + 1][0], acc[ct][2 * b + 1][1]}), b1 = mish_f2(f32x2{acc[ct][2 * b + 1][2], acc[ct][2 * b + 1][3]});
+      const h8 v = {(_Float16)a0[0], (_Float16)b0[0], (_Float16)a0[1], (_Float16)b0[1],
+                    (_Float16)a1[0], (_Float16)b1[0], (_Float16)a1[1], (_Float16)b1[1]};
+      const int t = lg + b * T::LG;
+      *(h8*)(smem + (uint32_t)((cg * 64 + ct * 16 + n) * TT_STRIDE + (t * 32 + 8 * q) * 2)) = v;
     }
     __builtin_amdgcn_sched_barrier(0);
   }

@@ -194,6 +194,7 @@ struct BlockPlan {
   //   on a fused block: the run's first block carries the head conv (head_of = that broadcast block,
   //   its stream lies right before stream_off), the run's last block the tail conv (right after).
   bool first_fused = false, last_fused = false;
+  bool dense_fused = false;   // C = 256: the dense runs in that tail as well (no k_bdense launch, t never stored)
   int head_of = -1, tail_of = -1;
   size_t head_bytes = 0, tail_bytes = 0;
 };
@@ -417,6 +418,29 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
         tail_stream = f0;
         tail_of = i;
         bp.first_fused = true;
+        // C = 256: the dense rides in that tail too (k_block, tail_dense).  Its stream there:
+        // [conv_first pass 0 (K slices 0, 1)] [dense] [conv_first pass 1 (K slices 0, 1)] [dense], the dense matrix
+        // with its K index = the act buffer's padded board row r = 20 y + x (zero rows for x = 19 and r >= 379)
+        static const bool no_dfuse = getenv("P3HIP_NO_DFUSE") != nullptr;
+        if (C == 256 && Cb == 128 && !no_dfuse) {
+          bp.dense_fused = true;
+          std::vector<_Float16> dpad;
+          for (int jp = 0; jp < 3; ++jp)
+            for (int q = 0; q < 24; ++q)
+              for (int h = 0; h < 2; ++h)
+                for (int jj = 0; jj < 128; ++jj)
+                  for (int el = 0; el < 8; ++el) {
+                    const int r = q * 16 + h * 8 + el, y = r / 20, x = r % 20, j = jp * 128 + jj;
+                    const bool on_board = x < 19 && y < 19;
+                    float v = (on_board && j < kNLoc) ? dw.data[(size_t)(y * 19 + x) * kNLoc + j] : 0.0f;
+                    dpad.push_back((_Float16)v);
+                  }
+          tail_stream.clear();
+          for (int cp = 0; cp < 2; ++cp) {
+            for (int ip = 0; ip < 2; ++ip) pack_segment(tail_stream, W(0, 1, C, C), 1, 1, C, C, ip * Cb, Cb, cp * Cb, Cb);
+            tail_stream.insert(tail_stream.end(), dpad.begin(), dpad.end());
+          }
+        }
       }
       flush_run();
       if (fused_neighbours && i + 1 < wf.nblocks && !wf.is_broadcast(i + 1)) {
@@ -558,6 +582,13 @@ p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
     a.tout = e->d_t;
     a.tail_scale = e->dev<float>(bb.bn[0].scale_off);
     a.tail_shift = e->dev<float>(bb.bn[0].shift_off);
+    if (bb.dense_fused) {
+      a.tail_dense = 1;
+      a.uout = e->d_u;
+      a.dense_bias = e->dev<float>(bb.dense_bias_off);
+      a.dense_scale = e->dev<float>(bb.bn[1].scale_off);
+      a.dense_shift = e->dev<float>(bb.bn[1].shift_off);
+    }
     a.nms_total += (int)(lb.tail_bytes / ms_bytes);
   }
   {
@@ -629,7 +660,8 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
       d.wstream = e->d_arena + bp.stream2_off; d.nms_total = bp.nms2;
       d.bias = e->dev<float>(bp.dense_bias_off);
       d.scale = e->dev<float>(bp.bn[1].scale_off); d.shift = e->dev<float>(bp.bn[1].shift_off);
-      if (!e->check(p3::launch_bdense(C, d, grid_for(e, npos, 1), s), "launch bdense")) return false;
+      if (!(bp.first_fused && bp.dense_fused) &&
+          !e->check(p3::launch_bdense(C, d, grid_for(e, npos, 1), s), "launch bdense")) return false;
       p3::Conv1x1Args c1{};
       c1.in = e->d_u; c1.out16 = e->d_x; c1.npos = npos;
       c1.wstream = e->d_arena + bp.stream3_off; c1.nms_total = bp.nms3;
@@ -1156,9 +1188,14 @@ double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
   int nbconv = 0;
   for (const BlockPlan& b : e->blocks) nbconv += (b.head_of >= 0) + (b.tail_of >= 0);
   const double bconv_per_launch = launches ? (double)nbconv * iters / launches : 0.0;
+  // ... and their dense where it rides in the tail (algorithmic 361 x 361 per channel, not the padded K = 384)
+  int ndense = 0;
+  for (const BlockPlan& b : e->blocks) ndense += b.kind == 3 && b.first_fused && b.dense_fused;
+  const double dense_per_launch = launches ? (double)ndense * iters / launches : 0.0;
   if (flops_per_launch)
     *flops_per_launch = 2.0 * n_positions * kNLoc *
-                        (blocks_per_launch * (n3 * 9.0 * wf.Cb * wf.Cb + 2.0 * wf.C * wf.Cb) + bconv_per_launch * (double)wf.C * wf.C);
+                        (blocks_per_launch * (n3 * 9.0 * wf.Cb * wf.Cb + 2.0 * wf.C * wf.Cb) + bconv_per_launch * (double)wf.C * wf.C +
+                         dense_per_launch * (double)wf.C * kNLoc);
   if (kernel_name) *kernel_name = p3::block_kernel_name(wf.C, bp->kind, wf.inner);
   return launches ? total_ms / launches : -1.0;
 }

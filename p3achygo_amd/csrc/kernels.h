@@ -49,6 +49,14 @@ struct BlockArgs {
   _Float16* tout;
   const float* tail_scale;
   const float* tail_shift;
+  // tail_dense (C = 256 only): the broadcast block's dense and its bn1 + mish run in the tail as well — u goes to
+  // uout, nothing to tout; the tail's stream is [conv_first pass 0][dense][conv_first pass 1][dense], the dense
+  // matrix packed over the act buffer's 384 padded board rows (engine.cpp)
+  int tail_dense;
+  _Float16* uout;
+  const float* dense_bias;    // [361]
+  const float* dense_scale;   // folded bn1 [C]
+  const float* dense_shift;
   // start-up stagger (shader-clock cycles per step, 0 = none): workgroup b begins (b / 8) % 8 steps late,
   // so the CUs of an XCD are not all in their HBM-bound phases (head / tail / residual traffic) at once
   int stagger;

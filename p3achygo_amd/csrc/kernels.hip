@@ -56,6 +56,80 @@ namespace p3 {
 //         A0 / A1 from the last block's expand epilogue like any next block; pass 1 re-reads x' as a
 //         position's first block does.
 // Each removes a launch that moved x through HBM twice (k_conv1x1) and the first block's own read.
+// ---- broadcast dense, shared by k_bdense and the fused tail of k_block -------------------------------
+constexpr int kTtStride = 784;  // bytes per channel row in LDS: 384 fp16 + 16 B pad
+constexpr int kTtChannels = 128;                          // channels resident per pass
+constexpr uint32_t kTtBytes = kTtChannels * kTtStride;    // 100,352
+
+// Tt seen as a conv act buffer: one slot per channel (128 per pass), K = 384 board points.
+struct GeoTt {
+  static constexpr int NW = 8, KMS = kKMS, RD = kRingDepth;
+  static constexpr int NPOS = 1, CB = 384, NCH = 48, SLOTB = kTtStride, PAD = 0, S = 1, NROWS = 128,
+                       NT_POS = 4, PADTOP = 0, PSLOTS = 128, ACT_BYTES = 128 * kTtStride, NT_TOTAL = 4;
+};
+
+// u[c][j] = mish(bn1(sum_i Tt[c][i] W[i][j] + b[j])) for the 128 channels in Tt (channel half `half` of position
+// `pos`), three passes of 128 dense columns j streamed through the ring, -> HBM in the piece layout.
+// p_bias [384], p_scale / p_shift [C]: LDS.  nch = channels of this pass that are real.
+template <int C>
+__device__ __forceinline__ void bdense_passes(Ring<16384>& ring, char* smem, const float* p_bias, const float* p_scale,
+                                              const float* p_shift, _Float16* __restrict__ u, int pos, int half, int nch) {
+  constexpr int CH = kTtChannels;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int jg = wid & 1;        // which 64 of the 128 j rows in this pass
+  const int ct = wid >> 1;       // channel tile (32 channels) 0..3
+  const int lr = lane & 31, h = lane >> 5;
+  const bool ct_active = ct * 32 < nch;
+#pragma unroll 1
+  for (int jp = 0; jp < 3; ++jp) {
+    // D[c][j] = sum_i Tt[c][i] * W[i][j]: the conv K loop with its operands swapped —
+    // "act buffer" = Tt (slot = channel, 48 chunks of 8 board points), "weights" = the
+    // 128 dense columns of this pass streamed through the ring; fragments are prefetched
+    // two k16 steps ahead exactly as in the conv kernels.
+    f32x16 acc2[2][1];
+    acc_zero<GeoTt, 128>(acc2);
+    conv_segment<GeoTt, 128, 1, 1, true>(ring, smem, acc2);
+    if (!ct_active) continue;
+    const f32x16 acc[2] = {acc2[0][0], acc2[1][0]};
+    // epilogue: rows = channel (regs), cols = j (lanes)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int j = jp * 128 + jg * 64 + mt * 32 + lr;
+      if (j >= kNLoc) continue;
+      const float bj = p_bias[j];
+      // channel blocks g4 = 2*gp and 2*gp + 1: each lane's quad is one 8-byte half of a
+      // block's piece; after the swap lanes 0-31 hold the whole piece of block 2*gp, lanes
+      // 32-63 that of block 2*gp + 1 (see epilogue_store in conv_core.h)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        h4 o[2];
+        {
+          const int g4 = 2 * gp;
+          const int c = half * CH + ct * 32 + g4 * 8 + h * 4;
+          const f32x4 sc0 = scale_log2e(*(const f32x4*)(p_scale + c)), sh0 = scale_log2e(*(const f32x4*)(p_shift + c));
+          const f32x4 sc1 = scale_log2e(*(const f32x4*)(p_scale + c + 8)), sh1 = scale_log2e(*(const f32x4*)(p_shift + c + 8));
+          const f32x4 v0 = {acc[mt][g4 * 4] + bj, acc[mt][g4 * 4 + 1] + bj, acc[mt][g4 * 4 + 2] + bj, acc[mt][g4 * 4 + 3] + bj};
+          const f32x4 v1 = {acc[mt][g4 * 4 + 4] + bj, acc[mt][g4 * 4 + 5] + bj, acc[mt][g4 * 4 + 6] + bj, acc[mt][g4 * 4 + 7] + bj};
+          bn_mish8_l2(v0, v1, sc0, sh0, sc1, sh1, o[0], o[1]);
+        }
+        half_swap32(o[0], o[1]);
+        const h8 piece = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
+        const int cb = (half * CH + ct * 32) / 8 + 2 * gp + h;   // this lane's channel block
+        *(h8*)(u + ((size_t)pos * (C / 8) + cb) * (kNLoc * 8) + j * 8) = piece;
+      }
+    }
+  }
+}
+
+// dense bias per board point and folded bn1 per channel into LDS at `dst` ([384] + [C] + [C] floats)
+template <int C>
+__device__ __forceinline__ void bdense_stage_params(float* dst, const float* __restrict__ bias,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift) {
+  for (int i = threadIdx.x; i < 384; i += kWG) dst[i] = i < kNLoc ? bias[i] : 0.0f;
+  for (int i = threadIdx.x; i < C; i += kWG) { dst[384 + i] = scale[i]; dst[384 + C + i] = shift[i]; }
+}
+
 #ifdef P3_DIAG
 #define P3_STAMP(section, k)                                                                              \
   do {                                                                                                    \
@@ -199,7 +273,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       // previous block's last pass (any block but the launch's very first), and the two halves
       // of x (24 loads) in a position's first block
       // (after a fused tail the previous position ended with 12 stores only: 36)
-      ring_note_inflight(ring, from_hbm ? (npos_done == 0 ? 24 : (tail ? 36 : 48)) : 24);
+      // (a fused tail with the dense ends on its last pass's stores, a wave-dependent few: count the loads only)
+      ring_note_inflight(ring, from_hbm ? (npos_done == 0 ? 24 : (tail ? (a.tail_dense ? 24 : 36) : 48)) : 24);
       acc16_zero<NT>(acc);
       P3_STAMP(blk, 1);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
@@ -276,6 +351,54 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
         P3_STAMP(blk, 16);
         epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, act_next, nsc, nsh, CB);
         P3_STAMP(blk, 17);
+      }
+    }
+    if constexpr (BC && C == 256 && CB == 128 && NW == 8) {
+      if (tail && a.tail_dense) {
+        // ---- conv_first AND the dense of the broadcast block after the run -----------------------------
+        //   u = mish(bn1(Dense(t))), t = mish(W . mish(bn0_b(x'))), a 128-channel half at a time: the conv's
+        //   output pass is taken transposed (SWAP) and written channel-major over the act buffer — the dense
+        //   contracts over board points — then three passes of 128 dense columns run off the same ring
+        //   (bdense_passes, k_bdense's K loop and epilogue).  t never goes to HBM and the dense is not its own
+        //   launch (two launches of 148 us and 185 KB written + read per position and broadcast block less).
+        //   Both passes take their K slices as (half 0, half 1): nothing survives the dense in the act buffer.
+        //   The act buffer's zero halo is restored after each half (the next conv reads it).
+        f32x4 acc[4][NT];
+        float* prm = (float*)(smem + kTtBytes);   // behind Tt, inside the act buffer's bytes
+        static_assert(kTtBytes + (384 + 2 * C) * 4 <= (uint32_t)G::ACT_BYTES, "dense parameters fit behind Tt");
+        ring_note_inflight(ring, 24);   // the last expand pass's 12 residual loads and 12 stores
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+          if (half == 1) {
+            // x' again (L2): half 0 activated and written now, half 1 parked raw across the first K slice
+            ResRegs16<NT> xin;
+            EpiOut16<NT> A0;
+            residual_addr16<G, CB, NT>(xin, C, pos0, a.npos, 0);
+            residual_load16<NT>(xin, a.x);
+            activate_loaded16<G, CB, NT>(A0, xin, a.tail_scale, a.tail_shift, 0);
+            residual_addr16<G, CB, NT>(xin, C, pos0, a.npos, CB);
+            residual_load16<NT>(xin, a.x);
+            stash16<NT>(A1, xin);
+            epilogue_write16<G, CB, NT>(smem, A0, 0);
+            ring_note_inflight(ring, 12);
+          }
+          acc16_zero<NT>(acc);
+          conv_segment16<G, CB, 1, 1, true>(ring, smem, acc);
+          if (half == 1) activate_stashed16<G, CB, NT>(A1, a.tail_scale, a.tail_shift, CB);
+          lds_barrier();
+          epilogue_write16<G, CB, NT>(smem, A1, 0);
+          conv_segment16<G, CB, 1, 1, true>(ring, smem, acc);
+          lds_barrier();   // every wave is done with the activations
+          epilogue_tt16<G, CB, kTtStride, NT>(smem, acc);
+          bdense_stage_params<C>(prm, a.dense_bias, a.dense_scale, a.dense_shift);
+          // (the dense's first ring acquire is the barrier behind these writes)
+          bdense_passes<C>(ring, smem, prm, prm + 384, prm + 384 + C, a.uout, pos0, half, kTtChannels);
+          lds_barrier();   // every wave is done with Tt
+          act_zero<G>(smem);
+          lds_barrier();
+        }
+        P3_SPAN(2 + npos_done < 7 ? 2 + npos_done : 6);
+        continue;
       }
     }
     if (tail) {
@@ -646,22 +769,11 @@ __global__ void __launch_bounds__(NW * 64, 2) k_lconv(LConvArgs a) {
 //   MFMA orientation: D[c][j] = sum_i Tt[c][i] * Wt[j][i]  (A = activations transposed in
 //   LDS to [c][i], B = dense matrix rows streamed through the ring).
 // =======================================================================================
-constexpr int kTtStride = 784;  // bytes per channel row in LDS: 384 fp16 + 16 B pad
-
-// Tt seen as a conv act buffer: one slot per channel (128 per pass), K = 384 board points.
-struct GeoTt {
-  static constexpr int NW = 8, KMS = kKMS, RD = kRingDepth;
-  static constexpr int NPOS = 1, CB = 384, NCH = 48, SLOTB = kTtStride, PAD = 0, S = 1, NROWS = 128,
-                       NT_POS = 4, PADTOP = 0, PSLOTS = 128, ACT_BYTES = 128 * kTtStride, NT_TOTAL = 4;
-};
-
 template <int C>
 __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CH = 128;                       // channels resident per pass
-  constexpr uint32_t kTtBytes = CH * kTtStride;  // 100,352
+  constexpr int CH = kTtChannels;
   constexpr uint32_t kRingOff = kTtBytes;
-  constexpr int NQ = 24;                        // k16 steps over i (384)
   for (int i = threadIdx.x * 16; i < (int)kTtBytes; i += kWG * 16) *(f32x4*)(smem + i) = f32x4{0, 0, 0, 0};
   Ring<16384> ring;
   ring_init(ring, smem, a.wstream, a.nms_total, kRingOff);
@@ -670,14 +782,8 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
   float* p_bias = (float*)(smem + kRingOff + ring_bytes(128));
   float* p_scale = p_bias + 384;
   float* p_shift = p_scale + C;
-  for (int i = threadIdx.x; i < 384; i += kWG) p_bias[i] = i < kNLoc ? a.bias[i] : 0.0f;
-  for (int i = threadIdx.x; i < C; i += kWG) { p_scale[i] = a.scale[i]; p_shift[i] = a.shift[i]; }
+  bdense_stage_params<C>(p_bias, a.bias, a.scale, a.shift);
   lds_barrier();
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int jg = wid & 1;        // which 64 of the 128 j rows in this pass
-  const int ct = wid >> 1;       // channel tile (32 channels) 0..3
-  const int lr = lane & 31, h = lane >> 5;
 
   // Staging is software-pipelined like the conv kernels': the 12 16-byte loads of the next
   // 128-channel pass (next half or next position) are issued before the current pass's K loop
@@ -710,7 +816,6 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
       // channels of this pass (the last pass of C = 192 has 64: its upper channel tiles idle
       // but still take part in the ring's barriers)
       const int nch = (C - half * CH) < CH ? (C - half * CH) : CH;
-      const bool ct_active = ct * 32 < nch;
       lds_barrier();
       // ---- transpose-stage t[pos][cblk][loc][8] -> Tt[c][i] --------------------------
       {
@@ -736,45 +841,7 @@ __global__ void __launch_bounds__(kWG, 2) k_bdense(BDenseArgs a) {
         pair_load(npos, cblk0 + ((threadIdx.x >> 5) * 8 < C - nhalf * CH ? 0 : -(int)(threadIdx.x >> 5)));
         ring_note_xloads(ring);
       }
-#pragma unroll 1
-      for (int jp = 0; jp < 3; ++jp) {
-        // D[c][j] = sum_i Tt[c][i] * W[i][j]: the conv K loop with its operands swapped —
-        // "act buffer" = Tt (slot = channel, 48 chunks of 8 board points), "weights" = the
-        // 128 dense columns of this pass streamed through the ring; fragments are prefetched
-        // two k16 steps ahead exactly as in the conv kernels.
-        f32x16 acc2[2][1];
-        acc_zero<GeoTt, 128>(acc2);
-        conv_segment<GeoTt, 128, 1, 1, true>(ring, smem, acc2);
-        if (!ct_active) continue;
-        const f32x16 acc[2] = {acc2[0][0], acc2[1][0]};
-        // epilogue: rows = channel (regs), cols = j (lanes)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const int j = jp * 128 + jg * 64 + mt * 32 + lr;
-          if (j >= kNLoc) continue;
-          const float bj = p_bias[j];
-          // channel blocks g4 = 2*gp and 2*gp + 1: each lane's quad is one 8-byte half of a
-          // block's piece; after the swap lanes 0-31 hold the whole piece of block 2*gp, lanes
-          // 32-63 that of block 2*gp + 1 (see epilogue_store in conv_core.h)
-#pragma unroll
-          for (int gp = 0; gp < 2; ++gp) {
-            h4 o[2];
-            {
-              const int g4 = 2 * gp;
-              const int c = half * CH + ct * 32 + g4 * 8 + h * 4;
-              const f32x4 sc0 = scale_log2e(*(const f32x4*)(p_scale + c)), sh0 = scale_log2e(*(const f32x4*)(p_shift + c));
-              const f32x4 sc1 = scale_log2e(*(const f32x4*)(p_scale + c + 8)), sh1 = scale_log2e(*(const f32x4*)(p_shift + c + 8));
-              const f32x4 v0 = {acc[mt][g4 * 4] + bj, acc[mt][g4 * 4 + 1] + bj, acc[mt][g4 * 4 + 2] + bj, acc[mt][g4 * 4 + 3] + bj};
-              const f32x4 v1 = {acc[mt][g4 * 4 + 4] + bj, acc[mt][g4 * 4 + 5] + bj, acc[mt][g4 * 4 + 6] + bj, acc[mt][g4 * 4 + 7] + bj};
-              bn_mish8_l2(v0, v1, sc0, sh0, sc1, sh1, o[0], o[1]);
-            }
-            half_swap32(o[0], o[1]);
-            const h8 piece = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
-            const int cb = (half * CH + ct * 32) / 8 + 2 * gp + h;   // this lane's channel block
-            *(h8*)(a.u + ((size_t)pos * (C / 8) + cb) * (kNLoc * 8) + j * 8) = piece;
-          }
-        }
-      }
+      bdense_passes<C>(ring, smem, p_bias, p_scale, p_shift, a.u, pos, half, nch);
     }
   }
   lds_barrier();

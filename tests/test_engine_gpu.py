@@ -332,13 +332,14 @@ def test_broadcast_convs_inside_block_launches_match_their_own_launches(built, t
     the intermediates fall differently: the two outputs (each within LOGIT_TOL of the float64 oracle in
     the parity tests above) stay within LOGIT_TOL of each other — an indexing or weight-order slip
     would show as O(1) — for one and several positions per workgroup, btl and nbt blocks, both C = 128
-    workgroup forms."""
+    workgroup forms.  Likewise the C = 256 launches' fused dense against k_bdense as its own launch."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for label, extra in (("fused", {}), ("own", {"P3HIP_NO_BFUSE": "1"}), ("fused_wg8", {"P3HIP_C128_WG8": "1"})):
+    for label, extra in (("fused", {}), ("own", {"P3HIP_NO_BFUSE": "1"}), ("fused_wg8", {"P3HIP_C128_WG8": "1"}),
+                         ("dense_own", {"P3HIP_NO_DFUSE": "1"})):
         env = dict(os.environ)
-        for k in ("P3HIP_NO_BFUSE", "P3HIP_C128_WG8", "P3HIP_NO_FUSE"):
+        for k in ("P3HIP_NO_BFUSE", "P3HIP_C128_WG8", "P3HIP_NO_FUSE", "P3HIP_NO_DFUSE"):
             env.pop(k, None)
         env.update(extra)
         path = str(tmp_path / (label + ".npz"))
@@ -350,6 +351,11 @@ def test_broadcast_convs_inside_block_launches_match_their_own_launches(built, t
         assert not np.isnan(a).any() and not np.isnan(c).any()
         assert _logits_close(a[:, :1889], b[:, :1889]), name
         assert _logits_close(c[:, :1889], b[:, :1889]), name
+        # C = 256: the broadcast dense rides in the tail as well (tail_dense; P3HIP_NO_DFUSE = k_bdense as its
+        # own launch, t through HBM): conv_first taken transposed, the dense's K over the padded board rows
+        d = res["dense_own"][name]
+        assert not np.isnan(d).any()
+        assert _logits_close(a[:, :1889], d[:, :1889]), name
 
 
 @pytest.mark.gpu

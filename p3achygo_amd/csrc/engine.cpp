@@ -422,7 +422,7 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
         // [conv_first pass 0 (K slices 0, 1)] [dense] [conv_first pass 1 (K slices 0, 1)] [dense], the dense matrix
         // with its K index = the act buffer's padded board row r = 20 y + x (zero rows for x = 19 and r >= 379)
         static const bool no_dfuse = getenv("P3HIP_NO_DFUSE") != nullptr;
-        if (C == 256 && Cb == 128 && !no_dfuse) {
+        if (C == 256 && Cb == 128 && wf.btype == 0 && !no_dfuse) {   // btl blocks only (k_block's tail_dense)
           bp.dense_fused = true;
           std::vector<_Float16> dpad;
           for (int jp = 0; jp < 3; ++jp)

@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
         P3_STAMP(blk, 17);
       }
     }
-    if constexpr (BC && C == 256 && CB == 128 && NW == 8) {
+    if constexpr (BC && C == 256 && CB == 128 && NW == 8 && KIND == 0) {   // (nbt: the allocator parks A1 in scratch inside the block loop)
       if (tail && a.tail_dense) {
         // ---- conv_first AND the dense of the broadcast block after the run -----------------------------
         //   u = mish(bn1(Dense(t))), t = mish(W . mish(bn0_b(x'))), a 128-channel half at a time: the conv's
@@ -369,6 +369,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
         ring_note_inflight(ring, 24);   // the last expand pass's 12 residual loads and 12 stores
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
+          P3_STAMP(7, 16 * half);
           if (half == 1) {
             // x' again (L2): half 0 activated and written now, half 1 parked raw across the first K slice
             ResRegs16<NT> xin;
@@ -383,19 +384,28 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
             ring_note_inflight(ring, 12);
           }
           acc16_zero<NT>(acc);
+          P3_STAMP(7, 16 * half + 1);
           conv_segment16<G, CB, 1, 1, true>(ring, smem, acc);
+          P3_STAMP(7, 16 * half + 2);
           if (half == 1) activate_stashed16<G, CB, NT>(A1, a.tail_scale, a.tail_shift, CB);
           lds_barrier();
           epilogue_write16<G, CB, NT>(smem, A1, 0);
+          P3_STAMP(7, 16 * half + 3);
           conv_segment16<G, CB, 1, 1, true>(ring, smem, acc);
+          P3_STAMP(7, 16 * half + 4);
           lds_barrier();   // every wave is done with the activations
           epilogue_tt16<G, CB, kTtStride, NT>(smem, acc);
           bdense_stage_params<C>(prm, a.dense_bias, a.dense_scale, a.dense_shift);
+          P3_STAMP(7, 16 * half + 5);
           // (the dense's first ring acquire is the barrier behind these writes)
           bdense_passes<C>(ring, smem, prm, prm + 384, prm + 384 + C, a.uout, pos0, half, kTtChannels);
+          P3_STAMP(7, 16 * half + 6);
           lds_barrier();   // every wave is done with Tt
+          // (zeroing only the halo slots, or anything else that changes this tail's code, is to be checked against
+          // the block loop's register allocation: tests/test_kernel_resources_cpu.py)
           act_zero<G>(smem);
           lds_barrier();
+          P3_STAMP(7, 16 * half + 7);
         }
         P3_SPAN(2 + npos_done < 7 ? 2 + npos_done : 6);
         continue;

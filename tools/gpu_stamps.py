@@ -41,6 +41,15 @@ NAMES_HEAD = {1: "z loads + write slice 0", 2: "seg p0 K0", 4: "write slice 1 + 
 NAMES_TAIL = {1: "(entry)", 2: "seg p0 K0", 4: "barrier + write A1", 5: "seg p0 K1", 6: "mish + store p0", 7: "x' half 0 reload issue",
               8: "seg p1 K1", 10: "activate + write half 0", 11: "seg p1 K0", 12: "barrier + mish + store p1"}
 
+# the tail with the dense fused in (tail_dense): the same eight phases per channel half, slots 16 * half + k
+NAMES_TAIL_DENSE = {}
+for _h in range(2):
+    for _k, _n in {1: "x' reload, activate, write half 0 (second half only)", 2: "conv_first seg K0", 3: "barrier + write A1",
+                   4: "conv_first seg K1", 5: "barrier + mish -> Tt + dense parameters", 6: "dense: 3 column passes + u stores",
+                   7: "barrier + zero halo"}.items():
+        NAMES_TAIL_DENSE[16 * _h + _k] = f"half {_h}: {_n}"
+NAMES_TAIL_DENSE[16] = "(between the halves)"
+
 
 def report(title, sec, names):
     s = st[:, :, sec, :]
@@ -60,7 +69,9 @@ def report(title, sec, names):
 grand = report("head (conv_last of the broadcast block before the run)", 6, NAMES_HEAD)
 for blk in range(6):
     grand += report(f"block {blk}", blk, NAMES_BLK)
-grand += report("tail (conv_first of the broadcast block after the run)", 7, NAMES_TAIL)
+dense_tail = (st[:, :, 7, 16] > 0).all()
+grand += report("tail (conv_first%s of the broadcast block after the run)" % (" + dense" if dense_tail else ""), 7,
+                NAMES_TAIL_DENSE if dense_tail else NAMES_TAIL)
 # whole position: first stamp of the first section to last stamp of the last
 print(f"sum of phases {grand:.0f} cycles per position ({'zero' if zeros else 'random'} weights)")
 eng.close()

@@ -369,9 +369,10 @@ def main():
             else:
                 roof["traffic_live_unavailable"] = detail
         if kname.startswith("k_block"):
-            roof["launch_contents"] = ("residual blocks + the 1x1 convs of the neighbouring broadcast blocks (HBM-bound, "
-                                       "4.9 % of the FLOPs); blocks_only = the same launches with those convs as their own "
-                                       "launches (P3HIP_NO_BFUSE=1: slower forward pass, comparable with earlier rounds)")
+            roof["launch_contents"] = ("residual blocks + the 1x1 convs of the neighbouring broadcast blocks (HBM-bound) + the "
+                                       "dense of the broadcast block after the run (LDS-bound), 8.1 % of the FLOPs together; "
+                                       "blocks_only = the same launches with all of those as their own launches "
+                                       "(P3HIP_NO_BFUSE=1: slower forward pass, comparable with earlier rounds)")
         else:
             roof["launch_contents"] = ("one 3x3 layer conv (C_b -> C_b) of a layer-wise trunk: 4-wave workgroups of one position, "
                                        "two per CU; activations round-trip HBM between layers")

@@ -16,7 +16,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <memory>
 #include <unordered_set>
 #include <string>
 #include <vector>
@@ -208,6 +210,7 @@ struct p3hip_engine {
   WeightFile wf;
   int n_cu = 256;
   bool c128_wg8 = false;   // P3HIP_C128_WG8: C = 128 blocks as one 8-wave workgroup per CU (A/B timing)
+  bool runs_contiguous = false;   // build_plan laid every run's streams back to back (joined launches possible)
   bool bcast_fuse = true;  // P3HIP_NO_BFUSE clears it: broadcast 1x1 convs as their own launches (A/B, tests)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -345,29 +348,40 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
   std::vector<std::pair<size_t, std::vector<_Float16>>> run_streams;   // (block index, stream)
   std::vector<_Float16> head_stream, tail_stream;   // of the run being collected
   int head_of = -1, tail_of = -1;
+  // The runs' streams are laid out after the loop, all runs back to back ([head r][blocks r][tail r][head r + 1] ...):
+  // with everything of the broadcast blocks between them fused, one k_block launch walks them all (joined_launch).
+  std::vector<std::function<void()>> layout;
   auto flush_run = [&]() {
     if (!run_streams.empty()) {
-      int nms_unused = 0;
-      if (head_of >= 0) {
-        add_stream(ar, head_stream, nms_unused, Cb);
-        BlockPlan& b = e->blocks[run_streams.front().first];
-        b.head_of = head_of;
-        b.head_bytes = head_stream.size() * 2;
-        e->blocks[head_of].last_fused = true;
-      }
-      for (auto& rs : run_streams) {
-        BlockPlan& b = e->blocks[rs.first];
-        b.stream_off = add_stream(ar, rs.second, b.nms, Cb);
-        b.stream_bytes = rs.second.size() * 2;
-      }
-      if (tail_of >= 0) {
-        add_stream(ar, tail_stream, nms_unused, Cb);
-        BlockPlan& b = e->blocks[run_streams.back().first];
-        b.tail_of = tail_of;
-        b.tail_bytes = tail_stream.size() * 2;
-      }
+      auto rs_all = std::make_shared<std::vector<std::pair<size_t, std::vector<_Float16>>>>(std::move(run_streams));
+      auto hs = std::make_shared<std::vector<_Float16>>(std::move(head_stream));
+      auto ts = std::make_shared<std::vector<_Float16>>(std::move(tail_stream));
+      const int h_of = head_of, t_of = tail_of;
+      layout.push_back([&ar, e, rs_all, hs, ts, h_of, t_of, Cb]() {
+        int nms_unused = 0;
+        if (h_of >= 0) {
+          add_stream(ar, *hs, nms_unused, Cb);
+          BlockPlan& b = e->blocks[rs_all->front().first];
+          b.head_of = h_of;
+          b.head_bytes = hs->size() * 2;
+          e->blocks[h_of].last_fused = true;
+        }
+        for (auto& rs : *rs_all) {
+          BlockPlan& b = e->blocks[rs.first];
+          b.stream_off = add_stream(ar, rs.second, b.nms, Cb);
+          b.stream_bytes = rs.second.size() * 2;
+        }
+        if (t_of >= 0) {
+          add_stream(ar, *ts, nms_unused, Cb);
+          BlockPlan& b = e->blocks[rs_all->back().first];
+          b.tail_of = t_of;
+          b.tail_bytes = ts->size() * 2;
+        }
+      });
     }
     run_streams.clear();
+    head_stream.clear();
+    tail_stream.clear();
     head_of = tail_of = -1;
   };
   for (int i = 0; i < wf.nblocks; ++i) {
@@ -508,6 +522,8 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
     e->blocks.push_back(bp);
   }
   flush_run();
+  for (auto& f : layout) f();
+  e->runs_contiguous = true;
   // heads: conv_p | conv_g | value.conv  -> [C][96]
   {
     std::vector<float> w((size_t)C * 96);
@@ -564,6 +580,7 @@ p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
   a.t = e->d_s ? e->d_s : e->d_t;
   a.npos = npos;
   a.nblk = count;
+  a.nruns = 1;
   // the streams of consecutive fused blocks lie back to back in the arena (build_plan), the fused
   // broadcast convs' right before the run's first and right after its last block
   const BlockPlan& fb = e->blocks[first];
@@ -580,14 +597,14 @@ p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
     const BlockPlan& bb = e->blocks[lb.tail_of];
     a.tail = 1;
     a.tout = e->d_t;
-    a.tail_scale = e->dev<float>(bb.bn[0].scale_off);
-    a.tail_shift = e->dev<float>(bb.bn[0].shift_off);
+    a.tail_scale[0] = e->dev<float>(bb.bn[0].scale_off);
+    a.tail_shift[0] = e->dev<float>(bb.bn[0].shift_off);
     if (bb.dense_fused) {
       a.tail_dense = 1;
       a.uout = e->d_u;
-      a.dense_bias = e->dev<float>(bb.dense_bias_off);
-      a.dense_scale = e->dev<float>(bb.bn[1].scale_off);
-      a.dense_shift = e->dev<float>(bb.bn[1].shift_off);
+      a.dense_bias[0] = e->dev<float>(bb.dense_bias_off);
+      a.dense_scale[0] = e->dev<float>(bb.bn[1].scale_off);
+      a.dense_shift[0] = e->dev<float>(bb.bn[1].shift_off);
     }
     a.nms_total += (int)(lb.tail_bytes / ms_bytes);
   }
@@ -618,6 +635,76 @@ p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
     }
   }
   return a;
+}
+
+// Joined launch (C = 256 btl): the runs of fused blocks from `first` on, with the broadcast blocks between them inside
+// ONE k_block launch — possible when every such broadcast block has both its 1x1 convs AND its dense fused into the
+// neighbouring runs (then their streams lie back to back in the arena, build_plan).  Returns the number of plan
+// blocks covered (0: not joinable) and fills `a`.
+int joined_launch(p3hip_engine* e, size_t first, int npos, p3::BlockArgs* out) {
+  static const bool no_join = getenv("P3HIP_NO_JOIN") != nullptr || getenv("P3HIP_NO_FUSE") != nullptr;
+  if (no_join || !e->runs_contiguous) return 0;
+  std::vector<std::pair<size_t, int>> runs;   // (first block, count)
+  size_t bi = first;
+  int nb = 0;
+  while (bi < e->blocks.size() && (int)runs.size() < p3::kMaxRuns) {
+    const int kind = e->blocks[bi].kind;
+    if (kind != 0) break;
+    int n = 1;
+    while (bi + n < e->blocks.size() && e->blocks[bi + n].kind == kind) ++n;
+    if (n > p3::kMaxFuse || nb + n > p3::kMaxLaunchBlocks) break;
+    runs.emplace_back(bi, n);
+    nb += n;
+    bi += n;
+    // a broadcast block with everything fused, followed by another run?
+    if (bi + 1 < e->blocks.size() && e->blocks[bi].kind == 3 && e->blocks[bi].first_fused && e->blocks[bi].last_fused &&
+        e->blocks[bi].dense_fused && e->blocks[bi + 1].kind == 0) ++bi;
+    else break;
+  }
+  if (runs.size() < 2) return 0;
+  // the loop may have stepped over a broadcast block without taking the run behind it (kMaxRuns, block limit)
+  const size_t last_run_end = runs.back().first + runs.back().second;
+  p3::BlockArgs a = block_args(e, runs[0].first, runs[0].second, npos);   // head of run 0 (if any), stagger, stream start
+  a.nruns = (int)runs.size();
+  a.nms_total = 0;
+  a.tail = 0;
+  a.tail_dense = 1;
+  a.zin = e->d_u;
+  a.uout = e->d_u;
+  const size_t ms_bytes = (size_t)p3::block_macro_step_bytes(e->wf.C, e->c128_wg8);
+  int k = 0;
+  for (size_t r = 0; r < runs.size(); ++r) {
+    a.run_nblk[r] = runs[r].second;
+    const BlockPlan& fb = e->blocks[runs[r].first];
+    const BlockPlan& lb = e->blocks[runs[r].first + runs[r].second - 1];
+    if (fb.head_of >= 0) a.nms_total += (int)(fb.head_bytes / ms_bytes);
+    for (int b = 0; b < runs[r].second; ++b, ++k) {
+      const BlockPlan& bp = e->blocks[runs[r].first + b];
+      a.nms_total += (int)(bp.stream_bytes / ms_bytes);
+      for (int j = 0; j < p3::kMaxBlockLayers; ++j) {
+        a.blk[k].scale[j] = e->dev<float>(bp.bn[j].scale_off);
+        a.blk[k].shift[j] = e->dev<float>(bp.bn[j].shift_off);
+      }
+    }
+    if (r + 1 < runs.size() || lb.tail_of >= 0) {
+      const BlockPlan& bb = e->blocks[lb.tail_of];
+      a.nms_total += (int)(lb.tail_bytes / ms_bytes);
+      a.tail_scale[r] = e->dev<float>(bb.bn[0].scale_off);
+      a.tail_shift[r] = e->dev<float>(bb.bn[0].shift_off);
+      a.dense_bias[r] = e->dev<float>(bb.dense_bias_off);
+      a.dense_scale[r] = e->dev<float>(bb.bn[1].scale_off);
+      a.dense_shift[r] = e->dev<float>(bb.bn[1].shift_off);
+      if (r + 1 == runs.size()) a.tail = 1;   // the last run has a tail too (a broadcast block follows it)
+    }
+  }
+  // every run's streams must lie back to back: [head r][blocks r][tail r][head r+1] ...
+  for (size_t r = 0; r + 1 < runs.size(); ++r) {
+    const BlockPlan& lb = e->blocks[runs[r].first + runs[r].second - 1];
+    const BlockPlan& nf = e->blocks[runs[r + 1].first];
+    if (lb.stream_off + lb.stream_bytes + lb.tail_bytes + nf.head_bytes != nf.stream_off) return 0;
+  }
+  *out = a;
+  return (int)(last_run_end - first);
 }
 
 // Number of blocks the launch starting at block `first` covers: consecutive blocks of the fused
@@ -683,8 +770,11 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
         if (timed) hipEventRecord(e->blk_ev[2 * e->timed_blocks++ + 1], s);
       }
     } else {
-      const int run = fused_run(e, bi);
-      p3::BlockArgs a = block_args(e, bi, run, npos);
+      int run = fused_run(e, bi);
+      p3::BlockArgs a;
+      const int joined = joined_launch(e, bi, npos, &a);
+      if (joined > 0) run = joined;
+      else a = block_args(e, bi, run, npos);
 #ifdef P3_DIAG
       {
         static const int which = getenv("P3DIAG_LAUNCH") ? atoi(getenv("P3DIAG_LAUNCH")) : 1;
@@ -804,7 +894,9 @@ p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version
             e->check(hipEventCreate(&e->ev0), "hipEventCreate") &&
             e->check(hipEventCreate(&e->ev1), "hipEventCreate") &&
             e->check(hipMalloc((void**)&e->d_arena, ar.host.size()), "hipMalloc arena") &&
-            e->check(hipMemcpy(e->d_arena, ar.host.data(), ar.host.size(), hipMemcpyHostToDevice), "upload weights") &&
+            // on the engine's own stream: it is non-blocking (no implicit ordering with the null stream a plain
+            // hipMemcpy / hipMemset runs on), and the first run must find the weights there
+            e->check(hipMemcpyAsync(e->d_arena, ar.host.data(), ar.host.size(), hipMemcpyHostToDevice, e->stream), "upload weights") &&
             e->check(hipHostMalloc((void**)&e->h_feats, B * kFeatBytes, hipHostMallocDefault), "hipHostMalloc") &&
             e->check(hipHostMalloc((void**)&e->h_feats_compact, B * kFeatBytes, hipHostMallocDefault), "hipHostMalloc") &&
             e->check(hipHostMalloc((void**)&e->h_out, B * p3::kResultFloats * 4, hipHostMallocDefault), "hipHostMalloc") &&
@@ -817,8 +909,9 @@ p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version
             e->check(hipMalloc((void**)&e->d_out, B * p3::kOutStride * 4), "hipMalloc out");
   if (!ok) return fail(e->err);
   memset(e->h_feats, 0, B * kFeatBytes);
-  hipMemset(e->d_feats, 0, B * kFeatBytes);
-  hipMemset(e->d_out, 0, B * p3::kOutStride * 4);
+  if (!e->check(hipMemsetAsync(e->d_feats, 0, B * kFeatBytes, e->stream), "hipMemset feats") ||
+      !e->check(hipMemsetAsync(e->d_out, 0, B * p3::kOutStride * 4, e->stream), "hipMemset out") ||
+      !e->check(hipStreamSynchronize(e->stream), "upload sync")) return fail(e->err);
   e->slots = p3::SlotStates((int)B);
   e->slot_sym.assign(B, 0);
   e->row_sym.assign(B, 0);
@@ -896,7 +989,10 @@ int p3hip_cache_enable(p3hip_engine* e, int log2_entries) {
             e->check(hipHostMalloc((void**)&c.h_victim, B * 4, hipHostMallocDefault), "hipHostMalloc") &&
             e->check(hipHostMalloc((void**)&c.h_lists, 5 * B * 4, hipHostMallocDefault), "hipHostMalloc") &&
             e->check(hipHostMalloc((void**)&c.h_sym, B * 4, hipHostMallocDefault), "hipHostMalloc") &&
-            e->check(hipMemset(c.d_tkeys, 0, cap * 16), "hipMemset") && e->check(hipMemset(c.d_tmeta, 0, cap * 4), "hipMemset");
+            // (the engine's stream, as in p3hip_create: the table must be empty before the first probe kernel)
+            e->check(hipMemsetAsync(c.d_tkeys, 0, cap * 16, e->stream), "hipMemset") &&
+            e->check(hipMemsetAsync(c.d_tmeta, 0, cap * 4, e->stream), "hipMemset") &&
+            e->check(hipStreamSynchronize(e->stream), "cache table sync");
   if (!ok) {
     // free what was allocated (an over-large table fails at the records): a later, smaller enable starts clean
     const std::string why = e->err;

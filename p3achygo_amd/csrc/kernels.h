@@ -28,6 +28,9 @@ constexpr int kMaxBlockLayers = 8;
 // to a workgroup, so block b+1 of a position only needs block b of the SAME workgroup — no
 // grid-wide dependency, just the launch boundaries (ramp, tail, cold ring) saved.
 constexpr int kMaxFuse = 6;
+// Joined launches (C = 256 btl, broadcast dense fused): up to kMaxRuns runs of blocks with the broadcast blocks
+// between them inside ONE launch — a position goes through the whole trunk in its workgroup.
+constexpr int kMaxRuns = 4, kMaxLaunchBlocks = 12;
 struct BlockParams {
   const float* scale[kMaxBlockLayers];  // folded BN of conv j's prologue
   const float* shift[kMaxBlockLayers];
@@ -39,7 +42,9 @@ struct BlockArgs {
   int nblk;
   const void* wstream;  // the packed weight streams of the launch's blocks, back to back
   int nms_total;        // their total length in macro-steps (the ring walks them circularly)
-  BlockParams blk[kMaxFuse];
+  BlockParams blk[kMaxLaunchBlocks];   // all runs' blocks, in order
+  int nruns;            // >= 1; > 1: joined launch, run r has run_nblk[r] blocks (nblk is unused)
+  int run_nblk[kMaxRuns];
   // The 1x1 convs of the broadcast blocks next to the run ride in the same launch (k_block's BC
   // form): `head` = conv_last of the broadcast block BEFORE the run (x += W . zin, zin = k_bdense's
   // output, its stream first in wstream), `tail` = conv_first of the broadcast block AFTER it
@@ -47,16 +52,16 @@ struct BlockArgs {
   int head, tail;
   const _Float16* zin;
   _Float16* tout;
-  const float* tail_scale;
-  const float* tail_shift;
+  const float* tail_scale[kMaxRuns];   // [r]: of the broadcast block that ends run r
+  const float* tail_shift[kMaxRuns];
   // tail_dense (C = 256 only): the broadcast block's dense and its bn1 + mish run in the tail as well — u goes to
   // uout, nothing to tout; the tail's stream is [conv_first pass 0][dense][conv_first pass 1][dense], the dense
   // matrix packed over the act buffer's 384 padded board rows (engine.cpp)
   int tail_dense;
   _Float16* uout;
-  const float* dense_bias;    // [361]
-  const float* dense_scale;   // folded bn1 [C]
-  const float* dense_shift;
+  const float* dense_bias[kMaxRuns];    // [361]
+  const float* dense_scale[kMaxRuns];   // folded bn1 [C]
+  const float* dense_shift[kMaxRuns];
   // start-up stagger (shader-clock cycles per step, 0 = none): workgroup b begins (b / 8) % 8 steps late,
   // so the CUs of an XCD are not all in their HBM-bound phases (head / tail / residual traffic) at once
   int stagger;
@@ -70,6 +75,7 @@ struct BlockArgs {
   // the phase boundaries of its second position: stamps[((wg * 8 + wave) * 8 + section) * 32 + k],
   // section = block index (0..5), 6 = head, 7 = tail.  Never read by the kernel.
   unsigned long long* stamps;
+  int stamp_run;        // joined launches: the run whose phases are stamped
   // spans[wg * 16 + k], every workgroup (up to 512), wave 0: k = 0 kernel entry, 1 ring ready, 2 + p end of
   // the workgroup's position p (p < 5), 7 exit in shader-clock ticks (s_memtime; not comparable across XCDs);
   // [8 + k] the same instants on the 100 MHz device-wide counter (s_memrealtime)

@@ -133,7 +133,7 @@ __device__ __forceinline__ void bdense_stage_params(float* dst, const float* __r
 #ifdef P3_DIAG
 #define P3_STAMP(section, k)                                                                              \
   do {                                                                                                    \
-    if (a.stamps && blockIdx.x < kStampWgs && npos_done == 1 && (threadIdx.x & 63) == 0)                 \
+    if (a.stamps && blockIdx.x < kStampWgs && npos_done == 1 && run == a.stamp_run && (section) < kStampSections && (threadIdx.x & 63) == 0) \
       a.stamps[((blockIdx.x * 8 + (threadIdx.x >> 6)) * kStampSections + (section)) * kStampSlots + (k)] = \
           __builtin_amdgcn_s_memtime();                                                                   \
   } while (0)
@@ -175,11 +175,20 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
   int npos_done = 0;
   for (int pos0 = blockIdx.x * NPOS; pos0 < a.npos; pos0 += gridDim.x * NPOS, ++npos_done) {
     EpiOut16<NT> A1;   // activated reduce input, channel half 1, made by the previous block's expand
-    const bool head = BC && a.head, tail = BC && a.tail;
     if (NW == 4 && a.pair_turns) {   // whose turn at the higher priority (kernels.h)
       if ((blockIdx.x >= gridDim.x / 2) != (bool)(npos_done & 1)) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
     }
+    // Runs: a launch is one run of blocks with an optional head / tail (a.head, a.tail), or — joined launches,
+    // a.nruns > 1 — several runs with the broadcast blocks between them inside: run r > 0 begins with the head
+    // (conv_last) of the broadcast block whose tail (conv_first + dense) ended run r - 1 for this position.
+    const int nruns = BC ? a.nruns : 1;
+    const bool launch_tail = BC && a.tail;
+    int blk0 = 0;   // index of the run's first block in a.blk (an index, not a pointer: a.blk stays in the kernarg segment)
+#pragma unroll 1
+    for (int run = 0; run < nruns; ++run) {
+    const int nblk = (BC && nruns > 1) ? a.run_nblk[run] : a.nblk;
+    const bool head = BC && (run > 0 || a.head), tail = BC && (run + 1 < nruns || a.tail);
     if (head) {
       // ---- conv_last of the broadcast block before the run: x' = x + W . z ----------------------
       // Both K slices of z are requested together (one exposed latency).  Pass 0 runs slice 0 then
@@ -213,7 +222,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       P3_STAMP(6, 4);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
       P3_STAMP(6, 5);
-      epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, false, a.blk[0].scale[0], a.blk[0].shift[0], 0);
+      epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, false, a.blk[blk0].scale[0], a.blk[blk0].shift[0], 0);
       P3_STAMP(6, 6);
       residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, 0);
       residual_load16<NT>(rr, a.zin);
@@ -231,7 +240,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       P3_STAMP(6, 10);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
       P3_STAMP(6, 11);
-      epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, true, a.blk[0].scale[0], a.blk[0].shift[0], CB);
+      epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, true, a.blk[blk0].scale[0], a.blk[blk0].shift[0], CB);
       P3_STAMP(6, 12);
       {
         // half 0 of x' again (the lanes that stored it read it back), activated for the first block
@@ -239,17 +248,17 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
         EpiOut16<NT> A0;
         residual_addr16<G, CB, NT>(xin, C, pos0, a.npos, 0);
         residual_load16<NT>(xin, a.x);
-        activate_loaded16<G, CB, NT>(A0, xin, a.blk[0].scale[0], a.blk[0].shift[0], 0);
+        activate_loaded16<G, CB, NT>(A0, xin, a.blk[blk0].scale[0], a.blk[blk0].shift[0], 0);
         lds_barrier();
         epilogue_write16<G, CB, NT>(smem, A0, 0);
       }
       P3_STAMP(6, 13);
     }
 #pragma unroll 1
-    for (int blk = 0; blk < a.nblk; ++blk) {
-      const BlockParams& bp = a.blk[blk];
+    for (int blk = 0; blk < nblk; ++blk) {
+      const BlockParams& bp = a.blk[blk0 + blk];
       const bool from_hbm = blk == 0 && !head;
-      const bool last = blk + 1 == a.nblk;
+      const bool last = blk + 1 == nblk;
       f32x4 acc[4][NT];
       P3_STAMP(blk, 0);
       // ---- reduce 1x1 (C -> CB): the act buffer is free here (barrier at the end of the
@@ -274,7 +283,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       // of x (24 loads) in a position's first block
       // (after a fused tail the previous position ended with 12 stores only: 36)
       // (a fused tail with the dense ends on its last pass's stores, a wave-dependent few: count the loads only)
-      ring_note_inflight(ring, from_hbm ? (npos_done == 0 ? 24 : (tail ? (a.tail_dense ? 24 : 36) : 48)) : 24);
+      ring_note_inflight(ring, from_hbm ? (npos_done == 0 ? 24 : (launch_tail ? (a.tail_dense ? 24 : 36) : 48)) : 24);
       acc16_zero<NT>(acc);
       P3_STAMP(blk, 1);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
@@ -326,8 +335,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       // and lands under the barrier that follows -------------------------------------------------
       P3_STAMP(blk, 11);
       const bool act_next = !last || tail;
-      const float* nsc = last ? (tail ? a.tail_scale : bp.scale[0]) : a.blk[blk + 1].scale[0];
-      const float* nsh = last ? (tail ? a.tail_shift : bp.shift[0]) : a.blk[blk + 1].shift[0];
+      const float* nsc = last ? (tail ? a.tail_scale[run] : bp.scale[0]) : a.blk[blk0 + blk + 1].scale[0];
+      const float* nsh = last ? (tail ? a.tail_shift[run] : bp.shift[0]) : a.blk[blk0 + blk + 1].shift[0];
       {
         ResRegs16<NT> rr;
         EpiOut16<NT> A0;
@@ -376,7 +385,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
             EpiOut16<NT> A0;
             residual_addr16<G, CB, NT>(xin, C, pos0, a.npos, 0);
             residual_load16<NT>(xin, a.x);
-            activate_loaded16<G, CB, NT>(A0, xin, a.tail_scale, a.tail_shift, 0);
+            activate_loaded16<G, CB, NT>(A0, xin, a.tail_scale[run], a.tail_shift[run], 0);
             residual_addr16<G, CB, NT>(xin, C, pos0, a.npos, CB);
             residual_load16<NT>(xin, a.x);
             stash16<NT>(A1, xin);
@@ -387,7 +396,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
           P3_STAMP(7, 16 * half + 1);
           conv_segment16<G, CB, 1, 1, true>(ring, smem, acc);
           P3_STAMP(7, 16 * half + 2);
-          if (half == 1) activate_stashed16<G, CB, NT>(A1, a.tail_scale, a.tail_shift, CB);
+          if (half == 1) activate_stashed16<G, CB, NT>(A1, a.tail_scale[run], a.tail_shift[run], CB);
           lds_barrier();
           epilogue_write16<G, CB, NT>(smem, A1, 0);
           P3_STAMP(7, 16 * half + 3);
@@ -395,11 +404,14 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
           P3_STAMP(7, 16 * half + 4);
           lds_barrier();   // every wave is done with the activations
           epilogue_tt16<G, CB, kTtStride, NT>(smem, acc);
-          bdense_stage_params<C>(prm, a.dense_bias, a.dense_scale, a.dense_shift);
+          bdense_stage_params<C>(prm, a.dense_bias[run], a.dense_scale[run], a.dense_shift[run]);
           P3_STAMP(7, 16 * half + 5);
           // (the dense's first ring acquire is the barrier behind these writes)
           bdense_passes<C>(ring, smem, prm, prm + 384, prm + 384 + C, a.uout, pos0, half, kTtChannels);
           P3_STAMP(7, 16 * half + 6);
+          // joined launches: the head of the next run reads this position's u back (other lanes of this workgroup):
+          // the stores are acknowledged by L2 before the barrier, the loads come after it
+          if (half == 1 && run + 1 < nruns) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           lds_barrier();   // every wave is done with Tt
           // (zeroing only the halo slots, or anything else that changes this tail's code, is to be checked against
           // the block loop's register allocation: tests/test_kernel_resources_cpu.py)
@@ -407,8 +419,11 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
           lds_barrier();
           P3_STAMP(7, 16 * half + 7);
         }
-        P3_SPAN(2 + npos_done < 7 ? 2 + npos_done : 6);
-        continue;
+        // (workgroup scope: the workgroup's waves share the CU's write-through vector cache, so the wait and the barrier
+        // above are the whole release / acquire.  An agent-scope acquire here — buffer_inv sc1 — also drops the XCD's
+        // L2 lines, the weight stream among them, and cost 3 % of the launch.)
+        blk0 += nblk;
+        continue;   // the next run
       }
     }
     if (tail) {
@@ -442,7 +457,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       P3_STAMP(7, 7);
       conv_segment16<G, CB, 1, 1>(ring, smem, acc);
       P3_STAMP(7, 8);
-      activate_stashed16<G, CB, NT>(A1, a.tail_scale, a.tail_shift, 0);
+      activate_stashed16<G, CB, NT>(A1, a.tail_scale[run], a.tail_shift[run], 0);
       lds_barrier();
       epilogue_write16<G, CB, NT>(smem, A1, 0);
       P3_STAMP(7, 10);
@@ -453,6 +468,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       epilogue_store16_mish<NT>(acc, tr, a.tout);
       P3_STAMP(7, 12);
     }
+    blk0 += nblk;
+    }   // run
     P3_SPAN(2 + npos_done < 7 ? 2 + npos_done : 6);
   }
   ring_drain();
@@ -1171,7 +1188,7 @@ static hipError_t launch_block_bc(const BlockArgs& a, int n_cu, hipStream_t s) {
 }
 template <int C, int CB, int KIND, int L, int NW>
 static hipError_t launch_block_t(const BlockArgs& a, int n_cu, hipStream_t s) {
-  if (a.head || a.tail) return launch_block_bc<C, CB, KIND, L, NW, true>(a, n_cu, s);
+  if (a.head || a.tail || a.nruns > 1) return launch_block_bc<C, CB, KIND, L, NW, true>(a, n_cu, s);
   return launch_block_bc<C, CB, KIND, L, NW, false>(a, n_cu, s);
 }
 

@@ -337,9 +337,9 @@ def test_broadcast_convs_inside_block_launches_match_their_own_launches(built, t
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for label, extra in (("fused", {}), ("own", {"P3HIP_NO_BFUSE": "1"}), ("fused_wg8", {"P3HIP_C128_WG8": "1"}),
-                         ("dense_own", {"P3HIP_NO_DFUSE": "1"})):
+                         ("dense_own", {"P3HIP_NO_DFUSE": "1"}), ("not_joined", {"P3HIP_NO_JOIN": "1"})):
         env = dict(os.environ)
-        for k in ("P3HIP_NO_BFUSE", "P3HIP_C128_WG8", "P3HIP_NO_FUSE", "P3HIP_NO_DFUSE"):
+        for k in ("P3HIP_NO_BFUSE", "P3HIP_C128_WG8", "P3HIP_NO_FUSE", "P3HIP_NO_DFUSE", "P3HIP_NO_JOIN"):
             env.pop(k, None)
         env.update(extra)
         path = str(tmp_path / (label + ".npz"))
@@ -356,6 +356,10 @@ def test_broadcast_convs_inside_block_launches_match_their_own_launches(built, t
         d = res["dense_own"][name]
         assert not np.isnan(d).any()
         assert _logits_close(a[:, :1889], d[:, :1889]), name
+        # ... and with everything of the broadcast blocks fused the whole trunk is ONE launch (joined runs: a position
+        # goes through all its blocks in one workgroup; P3HIP_NO_JOIN = one launch per run): the same code in the
+        # same order on the same values
+        assert np.array_equal(a, res["not_joined"][name]), name
 
 
 @pytest.mark.gpu

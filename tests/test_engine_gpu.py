@@ -514,6 +514,45 @@ def test_repeated_and_concurrent_runs_are_bit_identical(built, weight_files):
 
 
 @pytest.mark.gpu
+def test_first_run_of_an_engine_created_while_the_device_is_busy(built, weight_files):
+    """p3hip_create uploads the weight arena and clears its buffers through the engine's own (non-blocking) stream and
+    synchronises it before it returns.  It used to leave both on the null stream, which that stream never waits for:
+    an engine created while another kept the GPU busy could evaluate its first batch on weights that had not landed
+    (whole result rows off by O(1), seen in 4 of 6 runs of the test above once the block weight streams had moved to the
+    end of the arena).  Here: engines created one after another while a second thread runs forward passes back to back;
+    the FIRST batch of each must equal the reference bit for bit."""
+    from p3achygo_amd import engine, features
+    name = "b12c256btl3"
+    batch = 256
+    pos = features.random_positions(batch, seed=21, n_games=16)
+    ref_eng = engine.HipEngine(weight_files(name), batch)
+    ref_eng.load_all(pos); ref_eng.RunInference()
+    ref = np.stack([ref_eng.get_raw(s) for s in (0, 1, 100, batch - 1)])
+    stop = threading.Event()
+
+    def busy():
+        ref_eng.upload()
+        while not stop.is_set():
+            for _ in range(8):
+                ref_eng.forward_resident(batch)
+            ref_eng.sync()
+
+    th = threading.Thread(target=busy)
+    th.start()
+    try:
+        for _ in range(6):
+            eng = engine.HipEngine(weight_files(name), batch)
+            eng.load_all(pos); eng.RunInference()
+            got = np.stack([eng.get_raw(s) for s in (0, 1, 100, batch - 1)])
+            eng.close()
+            assert np.array_equal(got, ref)
+    finally:
+        stop.set()
+        th.join()
+        ref_eng.close()
+
+
+@pytest.mark.gpu
 def test_device_nn_cache_serves_hits_bit_identical_and_evaluates_only_misses(built, weight_files):
     """On-device NN cache (p3hip_cache_*; the reference's per-thread LRU of cc/nn/nn_interface.cc:107-132 moved into
     HBM).  A keyed position is evaluated once; later runs return the stored record bit for bit, with the symmetry

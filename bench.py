@@ -368,10 +368,14 @@ def main():
                 roof["traffic_counters"] = {k: detail[k] for k in ("fetch_size_kib_raw", "write_size_kib")}
             else:
                 roof["traffic_live_unavailable"] = detail
-        if kname.startswith("k_block"):
-            roof["launch_contents"] = ("residual blocks + the 1x1 convs of the neighbouring broadcast blocks (HBM-bound) + the "
-                                       "dense of the broadcast block after the run (LDS-bound), 8.1 % of the FLOPs together; "
-                                       "blocks_only = the same launches with all of those as their own launches "
+        if kname.startswith("k_block<256,128,btl"):
+            roof["launch_contents"] = ("ONE launch per forward pass: every residual block + the broadcast blocks' 1x1 convs "
+                                       "(HBM-bound) and dense (LDS-bound) between them, 8.1 % of the FLOPs together; "
+                                       "blocks_only = one launch per run of residual blocks with all of those as their own "
+                                       "launches (P3HIP_NO_BFUSE=1: slower forward pass, comparable with earlier rounds)")
+        elif kname.startswith("k_block"):
+            roof["launch_contents"] = ("residual blocks + the 1x1 convs of the neighbouring broadcast blocks (HBM-bound); "
+                                       "blocks_only = the same launches with those convs as their own launches "
                                        "(P3HIP_NO_BFUSE=1: slower forward pass, comparable with earlier rounds)")
         else:
             roof["launch_contents"] = ("one 3x3 layer conv (C_b -> C_b) of a layer-wise trunk: 4-wave workgroups of one position, "

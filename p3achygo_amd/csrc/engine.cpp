@@ -228,6 +228,8 @@ struct p3hip_engine {
   size_t init_stream_off = 0; int init_nms = 0;
   size_t game_w_off = 0, game_b_off = 0;
   size_t heads_stream_off = 0; int heads_nms = 0;
+  size_t heads_conv_a_off = 0, heads_image_off = 0;
+  bool heads_fused = false;   // k_headsx: the head convs inside the heads kernel (C <= 256; P3HIP_NO_HFUSE clears it)
   std::map<std::string, size_t> head_off;
 
   // buffers
@@ -540,6 +542,18 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
     for (int cp = 0; cp < 2; ++cp)
       for (int ip = 0; ip < C / CB; ++ip) pack_segment(s, w.data(), 1, 1, C, 96, ip * CB, CB, cp * 64, 64);
     e->heads_stream_off = add_stream(ar, s, e->heads_nms, 64);
+    // the same weights as MFMA 16x16x32 A fragments for k_headsx (the convs inside the heads kernel):
+    // [cout tile ct][k32 step][lane (n = lane & 15, q = lane >> 4)][8] = w[cin = 32 step + 8 q + e][cout = 16 ct + n]
+    if (p3::heads_fusable(C, wf.V)) {
+      std::vector<_Float16> af;
+      for (int ct = 0; ct < 6; ++ct)
+        for (int st = 0; st < C / 32; ++st)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int el = 0; el < 8; ++el)
+              af.push_back((_Float16)w[(size_t)(st * 32 + 8 * (lane >> 4) + el) * 96 + ct * 16 + (lane & 15)]);
+      e->heads_conv_a_off = ar.add(af.data(), af.size() * 2);
+      e->heads_fused = getenv("P3HIP_NO_HFUSE") == nullptr;
+    }
     FoldedBN g = fold_bn(ar, wf, "policy.gpool_bn", 32);
     e->head_off["gbn_scale"] = g.scale_off;
     e->head_off["gbn_shift"] = g.shift_off;
@@ -555,6 +569,34 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
     for (const auto& h : heads) {
       const Tensor& t = wf.get(h.name, h.n);
       e->head_off[h.name] = ar.add(t.data, t.size() * 4);
+    }
+    // k_headsx takes the same tensors as one image in its LDS order (kernels.h heads_image_floats)
+    if (p3::heads_fusable(C, wf.V) && wf.missing.empty()) {
+      std::vector<float> img;
+      auto put = [&](const char* name, size_t n, size_t pad = 0) {
+        const Tensor& t = wf.get(name, n);
+        img.insert(img.end(), t.data, t.data + n);
+        img.insert(img.end(), pad, 0.0f);
+      };
+      put("policy.gpool_dense.w", 2 * H * H); put("value.oq_embed.w", 2 * H * V); put("value.gamma_pre.w", 2 * H * V);
+      put("value.score_pre.w", (2 * H + 1) * V); put("value.oq_out.w", V * 14); put("value.gamma_out.w", V);
+      put("value.score_out.w", V); put("policy.out_pass.w", 4 * H); put("policy.opt_pass.w", 2 * H);
+      put("policy.out_moves.w", 2 * H); put("policy.opt_moves.w", H); put("value.own.w", H);
+      {
+        const float* gs = reinterpret_cast<const float*>(ar.host.data() + g.scale_off);
+        const float* gh = reinterpret_cast<const float*>(ar.host.data() + g.shift_off);
+        std::vector<float> tmp(gs, gs + H);
+        img.insert(img.end(), tmp.begin(), tmp.end());
+        tmp.assign(gh, gh + H);
+        img.insert(img.end(), tmp.begin(), tmp.end());
+      }
+      put("policy.gpool_dense.b", H); put("value.oq_embed.b", V); put("value.gamma_pre.b", V); put("value.score_pre.b", V);
+      put("value.oq_out.b", 14, 2);
+      if ((int)img.size() != p3::heads_image_floats(32, wf.V)) {
+        e->err = "internal error: heads image size";
+        return false;
+      }
+      e->heads_image_off = ar.add(img.data(), img.size() * 4);
     }
   }
   if (!wf.missing.empty()) {
@@ -797,8 +839,11 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
     p3::Conv1x1Args c{};
     c.in = e->d_x; c.out32 = e->d_hp; c.npos = npos;
     c.wstream = e->d_arena + e->heads_stream_off; c.nms_total = e->heads_nms;
-    if (!e->check(p3::launch_conv1x1(C, 2, c, e->n_cu, s), "launch head convs")) return false;
+    if (!e->heads_fused && !e->check(p3::launch_conv1x1(C, 2, c, e->n_cu, s), "launch head convs")) return false;
     p3::HeadsArgs h{};
+    h.x = e->d_x;
+    h.conv_a = e->d_arena + e->heads_conv_a_off;
+    h.image = e->dev<float>(e->heads_image_off);
     h.hp = e->d_hp; h.out = e->d_out; h.npos = npos; h.V = wf.V;
     auto F = [&](const char* n) { return e->dev<float>(e->head_off.at(n)); };
     h.gbn_scale = F("gbn_scale"); h.gbn_shift = F("gbn_shift");
@@ -814,7 +859,9 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
     h.gamma_out_w = F("value.gamma_out.w"); h.gamma_out_b = F("value.gamma_out.b");
     h.score_pre_w = F("value.score_pre.w"); h.score_pre_b = F("value.score_pre.b");
     h.score_out_w = F("value.score_out.w"); h.score_out_b = F("value.score_out.b");
-    if (!e->check(p3::launch_heads(h, npos, s), "launch k_heads")) return false;
+    if (e->heads_fused) {
+      if (!e->check(p3::launch_headsx(C, h, e->n_cu, s), "launch k_headsx")) return false;
+    } else if (!e->check(p3::launch_heads(h, npos, s), "launch k_heads")) return false;
   }
   return true;
 }

@@ -134,8 +134,20 @@ struct BDenseArgs {
   const float* shift;
 };
 
+// k_headsx stages the small head tensors as ONE image, in HeadsLds' order (kernels.hip): gd_w [2H][H], oq_embed_w
+// [2H][V], gamma_pre_w [2H][V], score_pre_w [2H+1][V], oq_out_w [V][14], gamma_out_w [V], score_out_w [V], pass_w
+// [2H][2], opt_pass_w [2H], moves_w [H][2], opt_moves_w [H], own_w [H], gbn_scale [H], gbn_shift [H], gd_b [H],
+// oq_embed_b [V], gamma_pre_b [V], score_pre_b [V], oq_out_b [14 + 2 pad]
+constexpr int heads_image_floats(int H, int V) {
+  return 2 * H * H + 2 * H * V + 2 * H * V + (2 * H + 1) * V + V * 14 + V + V + 4 * H + 2 * H + 2 * H + H + H + H + H + H + V + V + V + 16;
+}
+
 struct HeadsArgs {
   const float* hp;  // [npos][96 / 4][361][4]: channel quads, as k_conv1x1 (EPI 2) stores its accumulators
+  // k_headsx (the head convs inside): the residual stream and the 96 x C conv weights as MFMA A fragments
+  const _Float16* x;        // [npos][C/8][361][8]
+  const void* conv_a;       // [6 cout tiles][C/32 k32 steps][64 lanes][8] fp16
+  const float* image;       // heads_image_floats(32, V) floats, 16-byte aligned
   float* out;       // [npos][kOutStride]
   int npos;
   int V;
@@ -165,6 +177,8 @@ hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s);
 // layer-wise conv: (kw, cin, cout) in {(1,384,192), (3,192,192), (1,192,384)}; two positions per workgroup
 hipError_t launch_lconv(int kw, int cin, int cout, const LConvArgs& a, int n_cu, hipStream_t s);
 hipError_t launch_heads(const HeadsArgs& a, int grid, hipStream_t s);
+bool heads_fusable(int C, int V);
+hipError_t launch_headsx(int C, const HeadsArgs& a, int n_cu, hipStream_t s);
 
 // ---- on-device NN cache (engine.cpp p3hip_cache_*) -------------------------------------------------
 // Open-addressed table in HBM: 128-bit keys, kCacheWays consecutive entries probed per key, one result

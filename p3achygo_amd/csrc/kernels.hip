@@ -1168,6 +1168,328 @@ __global__ void __launch_bounds__(1024) k_heads(HeadsArgs a) {
 }
 
 // =======================================================================================
+// Heads with their 1x1 convs inside (C <= 256): k_headsx.  The three head convs (conv_p | conv_g | value.conv,
+// C -> 96, raw x in: PolicyHead.call model.py:783-812, ValueHead.call :887-979) are 18 MFLOP per position, but as
+// their own launch they read x (185 KB per position at C = 256) and write 139 KB of fp32 head activations that
+// k_heads then reads 1.5 times: 544 MB per 1024 positions, three quarters of it the hand-over.  Here a position's
+// conv runs on MFMA 16x16x32 with the activation fragments taken STRAIGHT from global memory — in x's channel-blocked
+// layout [C/8][361][8] a lane's 8 consecutive channels of one board point are 16 contiguous bytes, exactly a B
+// fragment — the 96 x C weights resident in LDS as A fragments, and everything k_heads did with the head activations
+// done on the accumulators: g is pooled (mean / max of mish(bn(g))) and v pooled raw as the tiles come, ownership is
+// finished per tile, p waits in registers (48 per lane) for the pooled bias and becomes the policy logits after the
+// small dense layers.  x is read once, nothing else moves: 189 MB per 1024 positions.
+// One 512-thread workgroup = two positions side by side (four waves each, 256 VGPRs a wave: p and the prefetched
+// fragments live in registers), one workgroup per CU.  The phases after the pooling are k_heads' own, from LDS.
+// Lane (n = lane & 15, q = lane >> 4) of location tile t: acc[ct][i] = head channel ct*16 + 4q + i at board point 16 t + n.
+// =======================================================================================
+template <int C, int H, int V>
+struct HeadsxLds {
+  using L = HeadsLds<H, V>;
+  static constexpr int kGroups = 2, NS = C / 32;
+  static constexpr int part = L::n_weights + kGroups * L::n_scratch;       // [group][wave][4 kinds][H] pooling partials
+  static constexpr int n_part = kGroups * 4 * 4 * H;
+  static constexpr size_t conv_off = ((size_t)(part + n_part) * 4 + 15) / 16 * 16;   // A fragments [6][NS][64 lanes][8] fp16
+  static constexpr size_t bytes = conv_off + (size_t)6 * NS * 1024;
+};
+
+template <int C, int H, int V>
+__global__ void __launch_bounds__(512, 2) k_headsx(HeadsArgs a) {
+  static_assert(H == 32 && C % 32 == 0, "head channels");
+  using L = HeadsLds<H, V>;
+  using X = HeadsxLds<C, H, V>;
+  constexpr int NS = X::NS;
+  extern __shared__ __attribute__((aligned(16))) float hl[];
+  const int tid = threadIdx.x, g = tid >> 8, t = tid & 255;
+  const int wid = t >> 6, lane = t & 63;
+  const int n = lane & 15, q = lane >> 4;
+  // the small head tensors arrive as one image in L's order (engine.cpp): one round of 16-byte loads instead of
+  // nineteen dependent little loops (k_heads' staging: a round trip to L2 each, ~30 us of a 110 us kernel)
+  static_assert(L::n_weights == heads_image_floats(H, V) && L::n_weights % 4 == 0, "image = HeadsLds");
+  {
+    const f32x4* src = (const f32x4*)a.image;
+    f32x4* dst = (f32x4*)hl;
+    for (int i = tid; i < L::n_weights / 4; i += 512) dst[i] = src[i];
+  }
+  {
+    const f32x4* src = (const f32x4*)a.conv_a;
+    f32x4* dst = (f32x4*)((char*)hl + X::conv_off);
+    for (int i = tid; i < 6 * NS * 64; i += 512) dst[i] = src[i];
+  }
+  const float pass_b0 = a.pass_b[0], opt_pass_b = a.opt_pass_b[0], gamma_out_b = a.gamma_out_b[0],
+              score_out_b = a.score_out_b[0];
+  float* sc = hl + L::n_weights + g * L::n_scratch;
+  float* part = hl + X::part + g * (4 * 4 * H);
+  const char* wlds = (const char*)hl + X::conv_off + lane * 16;
+  __syncthreads();
+
+  constexpr int NTILE = (kNLoc + 15) / 16;          // 23 location tiles
+  constexpr int TPW = (NTILE + 3) / 4;               // tiles per wave (6; the last wave has 5)
+  for (int pos2 = blockIdx.x * X::kGroups; pos2 < a.npos; pos2 += gridDim.x * X::kGroups) {
+    const bool live = pos2 + g < a.npos;
+    const int pos = live ? pos2 + g : a.npos - 1;   // an idle group recomputes the last position
+    float* __restrict__ out = a.out + (size_t)pos * kOutStride;
+    const _Float16* __restrict__ xp = a.x + (size_t)pos * C * kNLoc;
+    // per-lane constants of this lane's 8 channels (cout tiles 2u and 2u + 1 of a head: channels 16u' + 4q + i)
+    float bsc[2][4], bsh[2][4], ownw[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bsc[u][i] = hl[L::gbn_scale + 16 * u + 4 * q + i];
+        bsh[u][i] = hl[L::gbn_shift + 16 * u + 4 * q + i];
+        ownw[u][i] = hl[L::own_w + 16 * u + 4 * q + i];
+      }
+    float gs[2][4], gm[2][4], vs[2][4], vm[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { gs[u][i] = 0.0f; gm[u][i] = -3.0e38f; vs[u][i] = 0.0f; vm[u][i] = -3.0e38f; }
+    f32x4 P[TPW][2];   // the p channels of this wave's tiles, until the pooled bias is known
+    // activation fragments of one tile: k32 step s_ = channel blocks 4 s_ + q of board point 16 tile + n
+    // (two tiles per pass over the weights — half the LDS fragment reads — measured slower: the second accumulator
+    // set and fragment buffer spill; gpurun_out/hx_ab2.log)
+    auto xload = [&](h8 (&xb)[NS], int tile) {
+      int loc = tile * 16 + n;
+      if (loc >= kNLoc) loc = kNLoc - 1;   // pad columns of the last tile: computed, never used
+      const _Float16* src = xp + ((size_t)q * kNLoc + loc) * 8;
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) xb[s_] = *(const h8*)(src + (size_t)s_ * 4 * kNLoc * 8);
+    };
+    h8 xb[2][NS];
+    xload(xb[0], wid);
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+      const int tile = wid + 4 * k;
+      if (k + 1 < TPW) xload(xb[(k + 1) & 1], (tile + 4 < NTILE) ? tile + 4 : NTILE - 1);
+      f32x4 acc[6];
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_)
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct)
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const h8*)(wlds + (ct * NS + s_) * 1024), xb[k & 1][s_], acc[ct], 0, 0, 0);
+      const int loc = tile * 16 + n;
+      const bool ok = tile < NTILE && loc < kNLoc;
+      P[k][0] = acc[0];
+      P[k][1] = acc[1];
+      float ow = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float y = mish_f(acc[2 + u][i] * bsc[u][i] + bsh[u][i]);
+          const float v = acc[4 + u][i];
+          if (ok) {
+            gs[u][i] += y;
+            gm[u][i] = fmaxf(gm[u][i], y);
+            vs[u][i] += v;
+            vm[u][i] = fmaxf(vm[u][i], v);
+          }
+          ow += v * ownw[u][i];
+        }
+      ow += __shfl_xor(ow, 16);
+      ow += __shfl_xor(ow, 32);
+      if (ok && live && q == 0) out[kOffOwnership + loc] = tanhf(ow);
+    }
+    // pooled g / v: over the 16 board points of a lane row, then over the waves through LDS
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          gs[u][i] += __shfl_xor(gs[u][i], m);
+          gm[u][i] = fmaxf(gm[u][i], __shfl_xor(gm[u][i], m));
+          vs[u][i] += __shfl_xor(vs[u][i], m);
+          vm[u][i] = fmaxf(vm[u][i], __shfl_xor(vm[u][i], m));
+        }
+        if (n == 0) {
+          const int ch = 16 * u + 4 * q + i;
+          float* pw = part + wid * (4 * H);
+          pw[ch] = gs[u][i];
+          pw[H + ch] = gm[u][i];
+          pw[2 * H + ch] = vs[u][i];
+          pw[3 * H + ch] = vm[u][i];
+        }
+      }
+    __syncthreads();
+    if (t < 4 * H) {
+      const int kind = t / H, ch = t - kind * H;
+      const float p0 = part[kind * H + ch], p1 = part[4 * H + kind * H + ch], p2 = part[8 * H + kind * H + ch],
+                  p3 = part[12 * H + kind * H + ch];
+      float* dst = sc + ((kind < 2) ? L::gp : L::vp);
+      if ((kind & 1) == 0) dst[ch] = (p0 + p1 + p2 + p3) * (1.0f / kNLoc);
+      else dst[H + ch] = fmaxf(fmaxf(p0, p1), fmaxf(p2, p3));
+    }
+    __syncthreads();
+    // ---- small dense layers (k_heads) ------------------------------------------------
+    if (t < H) {
+      float s_ = hl[L::gd_b + t];
+#pragma unroll 8
+      for (int k = 0; k < 2 * H; ++k) s_ += sc[L::gp + k] * hl[L::gd_w + k * H + t];
+      sc[L::gbias + t] = s_;
+    } else if (t >= 64 && t < 64 + V) {
+      const int o = t - 64;
+      float s_ = hl[L::oq_embed_b + o], gmm = hl[L::gamma_pre_b + o], b = hl[L::score_pre_b + o];
+#pragma unroll 8
+      for (int k = 0; k < 2 * H; ++k) {
+        const float x = sc[L::vp + k];
+        s_ += x * hl[L::oq_embed_w + k * V + o];
+        gmm += x * hl[L::gamma_pre_w + k * V + o];
+        b += x * hl[L::score_pre_w + k * V + o];
+      }
+      sc[L::emb + o] = mish_f(s_);
+      sc[L::gpre + o] = mish_f(gmm);
+      sc[L::base + o] = b;
+    } else if (t == 192) {
+      float s0 = pass_b0, so = opt_pass_b;
+#pragma unroll 8
+      for (int k = 0; k < 2 * H; ++k) {
+        s0 += sc[L::gp + k] * hl[L::pass_w + k * 2];
+        so += sc[L::gp + k] * hl[L::opt_pass_w + k];
+      }
+      sc[L::pi + 361] = s0 - 3.0f;
+      sc[L::opt + 361] = so - 3.0f;
+    }
+    __syncthreads();
+    if (t < 14) {
+      float s_ = hl[L::oq_out_b + t];
+#pragma unroll 8
+      for (int k = 0; k < V; ++k) s_ += sc[L::emb + k] * hl[L::oq_out_w + k * 14 + t];
+      if (t < 2) sc[L::misc + t] = s_;
+      if (live) {
+        if (t < 2) out[kOffOutcomeLogits + t] = s_;
+        if (t == 5) out[kOffErr2] = 4.0f / (1.0f + __expf(-s_));
+      }
+    } else if (t == 64) {
+      float s_ = gamma_out_b;
+#pragma unroll 8
+      for (int k = 0; k < V; ++k) s_ += sc[L::gpre + k] * hl[L::gamma_out_w + k];
+      if (live) out[kOffGamma] = s_;
+      const float sp = s_ > 20.0f ? s_ : log1pf(__expf(s_));
+      sc[L::misc + 2] = fminf(sp, 10.0f);
+    }
+    // ---- policy logits from the p channels kept in registers (needs gbias only) ------------
+    {
+      float gb[2][4], mw[2][4], omw[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = 16 * u + 4 * q + i;
+          gb[u][i] = sc[L::gbias + c];
+          mw[u][i] = hl[L::moves_w + c * 2];
+          omw[u][i] = hl[L::opt_moves_w + c];
+        }
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {
+        const int tile = wid + 4 * k;
+        float pi = 0.0f, po = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float pm = mish_f(P[k][u][i] + gb[u][i]);
+            pi += pm * mw[u][i];
+            po += pm * omw[u][i];
+          }
+        pi += __shfl_xor(pi, 16);
+        pi += __shfl_xor(pi, 32);
+        po += __shfl_xor(po, 16);
+        po += __shfl_xor(po, 32);
+        const int loc = tile * 16 + n;
+        if (q == 0 && tile < NTILE && loc < kNLoc) {
+          sc[L::pi + loc] = pi;
+          sc[L::opt + loc] = po;
+        }
+      }
+    }
+    __syncthreads();   // misc[2] (gamma), pi, opt ready
+    // ---- score logits: 800 bins x V ---------------------------------------------------
+    {
+      const float gam = sc[L::misc + 2];
+      for (int sidx = t; sidx < 800; sidx += 256) {
+        const float sv = 0.05f * (float)(sidx - 400) + 0.025f;
+        float s_ = score_out_b;
+        const int z = launder(0);   // keeps the LDS reads inside the bin loop
+#pragma unroll 8
+        for (int k = 0; k < V; ++k)
+          s_ += mish_f(sc[L::base + z + k] + sv * hl[L::score_pre_w + (2 * H) * V + z + k]) * hl[L::score_out_w + z + k];
+        sc[L::logits + sidx] = gam * s_;
+      }
+    }
+    __syncthreads();
+    // ---- raw logits out + the three softmaxes, reductions fused ------------------------
+    float m3[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = t; i < 362; i += 256) {
+      const float p = sc[L::pi + i], o = sc[L::opt + i];
+      if (live) {
+        out[kOffMoveLogits + i] = p;
+        out[kOffOptLogits + i] = o;
+      }
+      m3[0] = fmaxf(m3[0], p);
+      m3[1] = fmaxf(m3[1], o);
+    }
+    for (int i = t; i < 800; i += 256) {
+      const float l = sc[L::logits + i];
+      if (live) out[kOffScoreLogits + i] = l;
+      m3[2] = fmaxf(m3[2], l);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) m3[r] = wave_max(m3[r]);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) sc[L::red + r * 4 + wid] = m3[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      m3[r] = fmaxf(fmaxf(sc[L::red + r * 4], sc[L::red + r * 4 + 1]),
+                    fmaxf(sc[L::red + r * 4 + 2], sc[L::red + r * 4 + 3]));
+    __syncthreads();   // red is rewritten below
+    float s3[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = t; i < 362; i += 256) {
+      const float e0 = __expf(sc[L::pi + i] - m3[0]), e1 = __expf(sc[L::opt + i] - m3[1]);
+      sc[L::pi + i] = e0;
+      sc[L::opt + i] = e1;
+      s3[0] += e0;
+      s3[1] += e1;
+    }
+    for (int i = t; i < 800; i += 256) {
+      const float e = __expf(sc[L::logits + i] - m3[2]);
+      sc[L::logits + i] = e;
+      s3[2] += e;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) s3[r] = wave_sum(s3[r]);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) sc[L::red + r * 4 + wid] = s3[r];
+    }
+    __syncthreads();
+    if (live) {
+      const float i0 = 1.0f / (sc[L::red + 0] + sc[L::red + 1] + sc[L::red + 2] + sc[L::red + 3]);
+      const float i1 = 1.0f / (sc[L::red + 4] + sc[L::red + 5] + sc[L::red + 6] + sc[L::red + 7]);
+      const float i2 = 1.0f / (sc[L::red + 8] + sc[L::red + 9] + sc[L::red + 10] + sc[L::red + 11]);
+      for (int i = t; i < 362; i += 256) {
+        out[kOffMoveProbs + i] = sc[L::pi + i] * i0;
+        out[kOffOptProbs + i] = sc[L::opt + i] * i1;
+      }
+      for (int i = t; i < 800; i += 256) out[kOffScoreProbs + i] = sc[L::logits + i] * i2;
+      if (t == 0) {
+        const float v0 = sc[L::misc], v1 = sc[L::misc + 1];
+        const float m = fmaxf(v0, v1);
+        const float e0 = __expf(v0 - m), e1 = __expf(v1 - m);
+        out[kOffValueProbs] = e0 / (e0 + e1);
+        out[kOffValueProbs + 1] = e1 / (e0 + e1);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =======================================================================================
 // Host-side launchers
 // =======================================================================================
 template <int C, int CB, int KIND, int L, int NW, bool BC>
@@ -1370,6 +1692,33 @@ static hipError_t launch_heads_t(const HeadsArgs& a, hipStream_t s) {
   const int grid = (a.npos + L::kGroups - 1) / L::kGroups;
   hipLaunchKernelGGL((k_heads<32, V>), dim3(grid), dim3(1024), L::bytes, s, a);
   return hipGetLastError();
+}
+
+template <int C, int V>
+static hipError_t launch_headsx_t(const HeadsArgs& a, int n_cu, hipStream_t s) {
+  using X = HeadsxLds<C, 32, V>;
+  static_assert(X::bytes <= 160 * 1024, "LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = set_lds(k_headsx<C, 32, V>, X::bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int groups = (a.npos + X::kGroups - 1) / X::kGroups;
+  hipLaunchKernelGGL((k_headsx<C, 32, V>), dim3(groups < n_cu ? groups : n_cu), dim3(512), X::bytes, s, a);
+  return hipGetLastError();
+}
+
+// heads with their convs inside (a.x, a.conv_a set): C in {128, 256}, V in {32, 48, 64}
+bool heads_fusable(int C, int V) { return (C == 128 || C == 256) && (V == 32 || V == 48 || V == 64); }
+hipError_t launch_headsx(int C, const HeadsArgs& a, int n_cu, hipStream_t s) {
+  if (C == 256 && a.V == 64) return launch_headsx_t<256, 64>(a, n_cu, s);
+  if (C == 256 && a.V == 48) return launch_headsx_t<256, 48>(a, n_cu, s);
+  if (C == 256 && a.V == 32) return launch_headsx_t<256, 32>(a, n_cu, s);
+  if (C == 128 && a.V == 64) return launch_headsx_t<128, 64>(a, n_cu, s);
+  if (C == 128 && a.V == 48) return launch_headsx_t<128, 48>(a, n_cu, s);
+  if (C == 128 && a.V == 32) return launch_headsx_t<128, 32>(a, n_cu, s);
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_heads(const HeadsArgs& a, int grid, hipStream_t s) {

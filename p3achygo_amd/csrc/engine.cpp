@@ -824,8 +824,12 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
         if (!e->d_stamps && hipMalloc((void**)&e->d_stamps, bytes) == hipSuccess) hipMemset(e->d_stamps, 0, bytes);
         constexpr size_t span_bytes = (size_t)p3::kSpanWgs * p3::kSpanSlots * 8;
         if (!e->d_spans && hipMalloc((void**)&e->d_spans, span_bytes) == hipSuccess) hipMemset(e->d_spans, 0, span_bytes);
-        a.spans = (e->launch_index == which) ? e->d_spans : nullptr;
-        a.stamps = (e->launch_index++ == which) ? e->d_stamps : nullptr;
+        // joined launches: ONE block launch per forward pass (index 0); P3DIAG_RUN picks the run whose phases are stamped
+        static const int which_run = getenv("P3DIAG_RUN") ? atoi(getenv("P3DIAG_RUN")) : 1;
+        const int idx = (a.nruns > 1) ? 0 : which;
+        a.stamp_run = (a.nruns > 1) ? which_run : 0;
+        a.spans = (e->launch_index == idx) ? e->d_spans : nullptr;
+        a.stamps = (e->launch_index++ == idx) ? e->d_stamps : nullptr;
       }
 #endif
       const bool timed = e->time_blocks && 2 * e->timed_blocks + 1 < (int)e->blk_ev.size();

@@ -1,6 +1,10 @@
 // board.cc — see board.h.  Each routine names the reference lines whose behaviour it keeps.
 #include "board.h"
 
+#ifdef __AVX2__
+#include <immintrin.h>
+#endif
+
 #include <atomic>
 
 #include <algorithm>
@@ -111,8 +115,21 @@ void SeenTable::Insert(uint64_t h) {
 
 bool Board::SeenContains(uint64_t h) const {
   if (h == 0) h = 1;
+#ifdef __AVX2__
+  // every legality check of the search and of the ladder reader ends here: four keys per compare (the list holds
+  // up to kLocalCap = 96; the scalar early-exit loop was 8 % of the self-play host's time)
+  {
+    const __m256i key = _mm256_set1_epi64x((long long)h);
+    int i = 0;
+    for (; i + 4 <= local_n_; i += 4)
+      if (_mm256_movemask_epi8(_mm256_cmpeq_epi64(_mm256_loadu_si256((const __m256i*)(local_ + i)), key))) return true;
+    for (; i < local_n_; ++i)
+      if (local_[i] == h) return true;
+  }
+#else
   for (int i = local_n_ - 1; i >= 0; --i)
     if (local_[i] == h) return true;
+#endif
   return base_ && base_->Contains(h);
 }
 
@@ -203,7 +220,25 @@ void Board::AddStone(int idx, Color color) {
   gid_[idx] = (int16_t)head;
   next_[idx] = next_[head];
   next_[head] = (int16_t)idx;
-  // exact recount
+  if (nf == 1) {
+    // One friendly group grows by a stone: the point stops being its liberty, and the stone's empty neighbours
+    // that no other stone of the group touches are new ones — the same count the walk below gives, without
+    // the walk (a quarter of the self-play host's time went into recounts and ladder liberty walks).
+    int l = libs_[head] - 1;
+    for (int k = 0; k < kNbr.n[idx]; ++k) {
+      const int q = kNbr.p[idx][k];
+      if (stones_[q] != kEmpty) continue;
+      bool touched = false;
+      for (int m = 0; m < kNbr.n[q]; ++m) {
+        const int r = kNbr.p[q][m];
+        touched |= r != idx && stones_[r] == color && gid_[r] == head;
+      }
+      l += !touched;
+    }
+    libs_[head] = (int16_t)l;
+    return;
+  }
+  // groups merged: exact recount (their liberty sets may overlap)
   g_marks.next();
   int l = 0, s = head;
   do {
@@ -538,15 +573,19 @@ thread_local bool t_ladder_exhausted = false;
 std::atomic<long> g_ladder_calls{0}, g_ladder_nodes{0}, g_ladder_max{0}, g_ladder_exhausted{0};
 
 struct LadderSolver {
+  // The first (up to) two liberties of the group in walk order.  Callers read groups of one or two liberties and
+  // use out[0] (and out[1]): the walk stops as soon as it has as many as the group's exact count says there are.
   static int FindLiberties(const Board& b, int head, int out[2]) {
-    g_marks2.next();
+    const int want = b.libs_[head] < 2 ? b.libs_[head] : 2;
     int n = 0, s = head;
+    out[0] = out[1] = head;   // (defined for a group without liberties: never the case for the callers)
+    if (want <= 0) return 0;
     do {
       for (int k = 0; k < kNbr.n[s]; ++k) {
         int q = kNbr.p[s][k];
-        if (b.stones_[q] == kEmpty && !g_marks2.test_and_set(q)) {
-          if (n < 2) out[n] = q;
-          ++n;
+        if (b.stones_[q] == kEmpty && (n == 0 || q != out[0])) {
+          out[n++] = q;
+          if (n == want) return n;
         }
       }
       s = b.next_[s];
@@ -591,23 +630,27 @@ struct LadderSolver {
       Board copy = board;
       return Solve(copy, g_color, Opp(color_to_move), root, l, depth + 1);
     };
+    // the last continuation of a node reads on in `board` itself: nothing looks at it afterwards (the caller's
+    // copy is dropped when this call returns), and a board copy per ply was a sixth of the host's time
+    auto last_continuation = [&](int l) { return Solve(board, g_color, Opp(color_to_move), root, l, depth + 1); };
     if (g_color != color_to_move) {  // attacker to move
       if (liberties > 2) return false;
       if (liberties <= 1) return true;
       int l[2];
       FindLiberties(board, gid, l);
-      return continuation(l[0]) || continuation(l[1]);
+      return continuation(l[0]) || last_continuation(l[1]);
     }
     // defender to move
     if (liberties > 1) return false;
     int l[2];
     FindLiberties(board, gid, l);
-    if (!continuation(l[0])) return false;
+    if (!continuation(l[0])) return false;   // (most nodes end here: the group walk below only after it)
     int atari[64];
-    int na = SurroundingInAtari(board, gid, atari);
+    const int na = SurroundingInAtari(board, gid, atari);
     for (int t = 0; t < na; ++t) {
       int nl[2];
       FindLiberties(board, atari[t], nl);
+      if (t + 1 == na) return last_continuation(nl[0]);
       if (!continuation(nl[0])) return false;
     }
     return true;

@@ -631,7 +631,7 @@ p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
   a.wstream = e->d_arena + fb.stream_off;
   if (fb.head_of >= 0) {
     a.head = 1;
-    a.zin = e->d_u;
+    a.zin = a.zin2 = e->d_u;
     a.wstream = e->d_arena + fb.stream_off - fb.head_bytes;
     a.nms_total += (int)(fb.head_bytes / ms_bytes);
   }
@@ -643,7 +643,7 @@ p3::BlockArgs block_args(p3hip_engine* e, size_t first, int count, int npos) {
     a.tail_shift[0] = e->dev<float>(bb.bn[0].shift_off);
     if (bb.dense_fused) {
       a.tail_dense = 1;
-      a.uout = e->d_u;
+      a.uout = a.uout2 = e->d_u;
       a.dense_bias[0] = e->dev<float>(bb.dense_bias_off);
       a.dense_scale[0] = e->dev<float>(bb.bn[1].scale_off);
       a.dense_shift[0] = e->dev<float>(bb.bn[1].shift_off);
@@ -711,8 +711,14 @@ int joined_launch(p3hip_engine* e, size_t first, int npos, p3::BlockArgs* out) {
   a.nms_total = 0;
   a.tail = 0;
   a.tail_dense = 1;
-  a.zin = e->d_u;
-  a.uout = e->d_u;
+  // u alternates between two buffers inside the launch (t's buffer is free: the dense is fused) when the launch
+  // neither starts with a head fed from outside nor ends with a tail read from outside; otherwise one buffer
+  const bool closed = !a.head && !(e->blocks[runs.back().first + runs.back().second - 1].tail_of >= 0);
+  _Float16* other = closed ? e->d_t : e->d_u;
+  a.zin2 = e->d_u;   // head of an even run: what the odd run before it wrote
+  a.uout = other;    // tail of an even run
+  a.zin = other;     // head of an odd run
+  a.uout2 = e->d_u;  // tail of an odd run
   const size_t ms_bytes = (size_t)p3::block_macro_step_bytes(e->wf.C, e->c128_wg8);
   int k = 0;
   for (size_t r = 0; r < runs.size(); ++r) {

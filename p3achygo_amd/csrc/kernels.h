@@ -50,7 +50,8 @@ struct BlockArgs {
   // output, its stream first in wstream), `tail` = conv_first of the broadcast block AFTER it
   // (tout = mish(W . mish(bn0(x))), bn0 = tail_scale/shift, its stream last in wstream).
   int head, tail;
-  const _Float16* zin;
+  const _Float16* zin;    // read by the head of an odd run (and of run 0: one launch per run reads zin, writes uout)
+  const _Float16* zin2;   // ... of an even run > 0 (joined launches: what the tail of the odd run before it wrote)
   _Float16* tout;
   const float* tail_scale[kMaxRuns];   // [r]: of the broadcast block that ends run r
   const float* tail_shift[kMaxRuns];
@@ -58,7 +59,8 @@ struct BlockArgs {
   // uout, nothing to tout; the tail's stream is [conv_first pass 0][dense][conv_first pass 1][dense], the dense
   // matrix packed over the act buffer's 384 padded board rows (engine.cpp)
   int tail_dense;
-  _Float16* uout;
+  _Float16* uout;    // written by the tail of an even run
+  _Float16* uout2;   // ... of an odd run (joined launches alternate)
   const float* dense_bias[kMaxRuns];    // [361]
   const float* dense_scale[kMaxRuns];   // folded bn1 [C]
   const float* dense_shift[kMaxRuns];

@@ -189,6 +189,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
     for (int run = 0; run < nruns; ++run) {
     const int nblk = (BC && nruns > 1) ? a.run_nblk[run] : a.nblk;
     const bool head = BC && (run > 0 || a.head), tail = BC && (run + 1 < nruns || a.tail);
+    // joined launches alternate between two u buffers (the tail of run r writes ubuf[r & 1], the head of run r + 1 reads
+    // it): no address is written twice within a launch, so nothing this CU read earlier in the launch can be stale
+    const _Float16* zin = BC ? ((run & 1) ? a.zin : a.zin2) : nullptr;
+    _Float16* uout = BC ? ((run & 1) ? a.uout2 : a.uout) : nullptr;
     if (head) {
       // ---- conv_last of the broadcast block before the run: x' = x + W . z ----------------------
       // Both K slices of z are requested together (one exposed latency).  Pass 0 runs slice 0 then
@@ -201,9 +205,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       {
         ResRegs16<NT> z0;
         residual_addr16<G, CB, NT>(z0, C, pos0, a.npos, 0);
-        residual_load16<NT>(z0, a.zin);
+        residual_load16<NT>(z0, zin);
         residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, CB);
-        residual_load16<NT>(rr, a.zin);
+        residual_load16<NT>(rr, zin);
         stash16<NT>(S, z0);
         lds_barrier();   // the act buffer is free: every wave is past the previous position's last segment
         epilogue_write16<G, CB, NT, true>(smem, S, 0);
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
       epilogue_store16_act<G, CB, NT>(acc, rr, a.x, A1, false, a.blk[blk0].scale[0], a.blk[blk0].shift[0], 0);
       P3_STAMP(6, 6);
       residual_addr16<G, CB, NT>(rr, C, pos0, a.npos, 0);
-      residual_load16<NT>(rr, a.zin);
+      residual_load16<NT>(rr, zin);
       stash16<NT>(S, rr);
       ring_note_inflight(ring, 12);
       acc16_zero<NT>(acc);
@@ -407,7 +411,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_block(BlockArgs a) {
           bdense_stage_params<C>(prm, a.dense_bias[run], a.dense_scale[run], a.dense_shift[run]);
           P3_STAMP(7, 16 * half + 5);
           // (the dense's first ring acquire is the barrier behind these writes)
-          bdense_passes<C>(ring, smem, prm, prm + 384, prm + 384 + C, a.uout, pos0, half, kTtChannels);
+          bdense_passes<C>(ring, smem, prm, prm + 384, prm + 384 + C, uout, pos0, half, kTtChannels);
           P3_STAMP(7, 16 * half + 6);
           // joined launches: the head of the next run reads this position's u back (other lanes of this workgroup):
           // the stores are acknowledged by L2 before the barrier, the loads come after it

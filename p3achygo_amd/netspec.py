@@ -83,6 +83,9 @@ CONFIGS: Dict[str, NetConfig] = {
         # launches with a broadcast block before them, after them and on both sides all occur
         NetConfig("test_b5c256nbt_i2", 5, 256, 128, 32, 48, 2, 2, "nbt"),
         NetConfig("test_b5c128btl1_i2", 5, 128, 64, 32, 32, 2, 1, "btl"),
+        # C = 256 btl with two inner layers and broadcast blocks 1 and 3: three one-block runs joined into ONE
+        # k_block launch (conv_last head, fused dense tail on both sides of a run), V = 48 heads
+        NetConfig("test_b5c256btl2_i2", 5, 256, 128, 32, 48, 2, 2, "btl"),
     ]
 }
 

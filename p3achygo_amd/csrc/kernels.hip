@@ -1412,15 +1412,22 @@ __global__ void __launch_bounds__(512, 2) k_headsx(HeadsArgs a) {
     __syncthreads();   // misc[2] (gamma), pi, opt ready
     // ---- score logits: 800 bins x V ---------------------------------------------------
     {
+      // two bins per lane and iteration, packed: 102 k mish per workgroup pass made this phase a quarter of the
+      // kernel (VALU-bound; the exp2 / rcp stay scalar, everything around them is v_pk_*)
       const float gam = sc[L::misc + 2];
-      for (int sidx = t; sidx < 800; sidx += 256) {
-        const float sv = 0.05f * (float)(sidx - 400) + 0.025f;
-        float s_ = score_out_b;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int s0 = t + 512 * pr, s1 = s0 + 256;
+        const f32x2 sv = {0.05f * (float)(s0 - 400) + 0.025f, 0.05f * (float)(s1 - 400) + 0.025f};
+        f32x2 acc = {score_out_b, score_out_b};
         const int z = launder(0);   // keeps the LDS reads inside the bin loop
 #pragma unroll 8
-        for (int k = 0; k < V; ++k)
-          s_ += mish_f(sc[L::base + z + k] + sv * hl[L::score_pre_w + (2 * H) * V + z + k]) * hl[L::score_out_w + z + k];
-        sc[L::logits + sidx] = gam * s_;
+        for (int k = 0; k < V; ++k) {
+          const float b = sc[L::base + z + k], w = hl[L::score_pre_w + (2 * H) * V + z + k], o = hl[L::score_out_w + z + k];
+          acc = __builtin_elementwise_fma(mish_f2(__builtin_elementwise_fma(sv, f32x2{w, w}, f32x2{b, b})), f32x2{o, o}, acc);
+        }
+        sc[L::logits + s0] = gam * acc[0];
+        if (s1 < 800) sc[L::logits + s1] = gam * acc[1];
       }
     }
     __syncthreads();

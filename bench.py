@@ -43,8 +43,10 @@ import numpy as np  # noqa: E402
 
 MODEL = "b12c256btl3"
 BATCH = 1024
-DEFAULT_GROUPS = GROUPS = 6          # game groups per GPU: forward passes of the others queued while one group is on the host
-                                     # (4 / 6 / 8 / 12 groups measured 217 / 222 / 220 / 220 k positions/s on one box)
+DEFAULT_GROUPS = GROUPS = 8          # game groups per GPU: forward passes of the others queued while one group is on the host
+                                     # (round 2: 4 / 6 / 8 / 12 groups 217 / 222 / 220 / 220 k positions/s on one box; round 3, the forward
+                                     # pass one long launch: 4 / 6 / 8 groups 225 / 237 / 241 k with 241 k engine-only, and the driver's
+                                     # 20-step window steadier with eight: 239-242 k against 209-242 k)
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 PF
 LADDER_BUDGET = 0       # ladder read-out work bound of the host: 0 = the reference's exact read-out (default)
 

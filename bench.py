@@ -6,16 +6,21 @@
 Headline (BASELINE.json metric): leaf positions evaluated per second through
 `p3hip_run` while the C++ self-play host (libp3host.so: Gumbel MCTS n=32, thousands of concurrent
 19x19 games) drives the HIP engine through its C ABI — host search + PCIe + engine, random-init
-b12c256btl3 weights, 1024 positions per engine batch (BASELINE.json configs[2]).  One "step" = one
-engine batch (`p3hip_run` over one group of 1024 games' leaf positions); the host keeps GROUPS
-groups in flight (GROUPS - 1 forward passes queued on the GPU while one group is on the host).
+b12c256btl3 weights, 1024 positions per engine batch (BASELINE.json configs[2]).  The host keeps GROUPS
+game groups in flight (GROUPS - 1 forward passes queued on the GPU while one group is on the host), and
+one "step" = one ROUND: one engine batch (`p3hip_run` over a group's 1024 leaf positions) of every
+group, GROUPS x 1024 positions (round 4; rounds 1-3 timed single batches, and a window of 20 batch
+completions on eight interleaving streams opened and closed at arbitrary phases of the streams' cycle:
+BENCH_r03's 263.9 k exceeded what its own kernel time allowed).
 Untimed: an advance phase that plays every game past its raw-policy opening (up to 30 moves of ONE
 evaluation each, self_play_thread.cc:44,363-366; at most --advance-limit batches per group), so that
 the timed steps are steady-state Gumbel n=32 search whatever K is, then W warm-up rounds (one batch per
-group each).  Then exactly K steps are timed inside the host: the window opens at the completion of the
-last warm-up batch and closes at the completion of the K-th engine batch after it, whichever groups those
-batches fall in (its own steady clock; every engine run ends with its stream drained), bracketed by
-barriers; the slowest rank's time is the job's time.  Games shard embarrassingly across GPUs (one
+group each).  Then exactly K rounds are timed inside the host: the window opens at the completion of the
+last warm-up batch — that group is the ANCHOR — and closes at the completion of the anchor's K-th batch
+after it (its own steady clock; every engine run ends with its stream drained), so both ends sit at the
+same phase of the groups' cycle; every batch of any group that completes inside is counted (K per group in
+steady state).  The line flags itself (`window_artifact`) if its per-batch time is below the dominant
+kernel's own launch time.  Barriers bracket the region; the slowest rank's time is the job's time.  Games shard embarrassingly across GPUs (one
 process, one engine set, one HIP stream set per device; no data-path collective): weak scaling.
 `--gpus N` without WORLD_SIZE in the environment starts the N rank processes itself (before anything
 touches the GPU); under torch.distributed.run it checks N against WORLD_SIZE.
@@ -198,7 +203,8 @@ def launch_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4096, help="timed engine batches (p3hip_run calls) per GPU")
+    ap.add_argument("--steps", type=int, default=512,
+                    help="timed ROUNDS per GPU: one engine batch (p3hip_run) of every game group each")
     ap.add_argument("--warmup", type=int, default=16, help="untimed warm-up rounds (one batch per game group each)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--groups", type=int, default=DEFAULT_GROUPS, help="game groups (engine instances / HIP streams) per GPU")
@@ -269,7 +275,7 @@ def main():
     steps = args.steps
     host_api.set_groups(GROUPS)
     host_api.set_ladder_budget(args.ladder_budget)
-    host_api.set_step_limit(steps)
+    host_api.set_step_rounds(steps)
     host_api.set_advance_limit(args.advance_limit)
     ladder0 = host_api.ladder_stats()
     sharding.barrier(shard)
@@ -280,7 +286,7 @@ def main():
                                seed=sharding.seed_for_rank(77, shard), device=local_rank)
     sync()
     wall = time.perf_counter() - wall0
-    host_api.set_step_limit(0)
+    host_api.set_step_rounds(0)
     host_api.set_advance_limit(0)
     ladder1 = host_api.ladder_stats()
     dt = sharding.max_over_ranks(shard, st.seconds)
@@ -300,7 +306,8 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{args.model} random-init, self-play: C++ host (Gumbel MCTS n=32, default k<=5, "
                                    f"selected k=5) -> p3hip_run over batches of {args.batch} leaf positions -> "
-                                   "results back to the search; one step = one engine batch",
+                                   f"results back to the search; one step = one round = one engine batch of each of the "
+                                   f"{GROUPS} game groups = {GROUPS * args.batch} positions",
                        "batch_per_gpu": args.batch, "concurrent_games_per_gpu": GROUPS * args.batch,
                        "game_groups_per_gpu": GROUPS, "host_threads_per_gpu": threads,
                        "host_cpus_of_rank0": [cpus[0], cpus[-1]] if cpus else None,
@@ -312,11 +319,12 @@ def main():
             "games_past_opening": totals[7], "games_total": n_gpus * GROUPS * args.batch,
             "advance_batches_untimed": totals[8],
             "finished_games": totals[2],
-            "engine_batches_completed": totals[3], "mean_batch_fill": totals[0] / max(steps * n_gpus, 1) / args.batch,
+            "engine_batches_completed": totals[3], "mean_batch_fill": totals[0] / max(totals[3], 1) / args.batch,
+            "ms_per_batch": dt / max(totals[3] / n_gpus, 1) * 1e3,
             "eval_cache_hits": totals[4], "ladder_readouts": totals[5], "ladder_budget_hits": totals[6],
             "seconds_timed": dt, "wall_s_incl_setup_advance_and_warmup": wall,
-            # the same K steps, per-step time from a least-squares line through all K + 1 completion instants instead of
-            # the first and the last (completions come in bursts: a 20-step window's end points are +-1 batch = +-5 %)
+            # the same K rounds, per-round time from a least-squares line through the anchor group's K + 1 completion
+            # instants instead of the first and the last
             "value_fit": totals[0] / dt_fit, "seconds_timed_fit": dt_fit,
         }
 
@@ -449,6 +457,9 @@ def main():
                               "full_net_tflops": eng_pps * total_flops / 1e12,
                               "conv3x3_mfma_frac": eng_pps * conv3_flops / 1e12 / (PEAK_FP16_MFMA_TFLOPS * n_gpus)}
         out.update(extras)
+        # self-check: a step cannot be shorter than the ONE trunk launch every batch must execute
+        if roof and roof.get("launch_ms") and roof.get("kernel", "").startswith("k_block"):
+            out["window_artifact"] = bool(out["ms_per_batch"] < 0.98 * roof["launch_ms"])
         out["roofline"] = roof
         out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -218,6 +218,7 @@ struct p3hip_engine {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   bool graph_failed = false, graph_warm = false;
+  const unsigned char* graph_feats = nullptr;   // the feature buffer the captured k_init reads (kernel arguments are baked in)
   // p3hip_time_trunk_kernel: event pairs around every fused-block launch of a forward pass
   std::vector<hipEvent_t> blk_ev;
   bool time_blocks = false;
@@ -884,7 +885,13 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
 bool run_forward(p3hip_engine* e, int npos) {
   const bool want = (e->flags & P3HIP_FLAG_LAUNCH_GRAPH) && npos == e->batch && !e->time_blocks && !e->graph_failed;
   if (!want) return enqueue_forward(e, npos);
-  if (e->graph_exec) return e->check(hipGraphLaunch(e->graph_exec, e->stream), "hipGraphLaunch");
+  // The capture bakes every kernel argument in, k_init's feature pointer among them, and run_cached points
+  // e->d_feats at the cache's gathered copy around its forward pass: a graph captured for one buffer must never be
+  // replayed for the other.  The graph serves the buffer it was captured on; the other goes out kernel by kernel.
+  if (e->graph_exec) {
+    if (e->d_feats != e->graph_feats) return enqueue_forward(e, npos);
+    return e->check(hipGraphLaunch(e->graph_exec, e->stream), "hipGraphLaunch");
+  }
   if (!e->graph_warm) {
     e->graph_warm = true;
     return enqueue_forward(e, npos);
@@ -905,6 +912,7 @@ bool run_forward(p3hip_engine* e, int npos) {
     return enqueue_forward(e, npos);   // nothing was executed by the capture
   }
   e->graph = g;
+  e->graph_feats = e->d_feats;
   return e->check(hipGraphLaunch(e->graph_exec, e->stream), "hipGraphLaunch");
 }
 

@@ -10,6 +10,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "conv_core.h"
 #include "conv16.h"
 
@@ -1503,18 +1505,28 @@ __global__ void __launch_bounds__(512, 2) k_headsx(HeadsArgs a) {
 // =======================================================================================
 // Host-side launchers
 // =======================================================================================
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE, and the launchers are called from many host threads
+// (bench.py: one driver thread per game group; an evaluation match: one engine per player, possibly on two devices):
+// one flag per (kernel instantiation, device ordinal), set after the attribute call succeeded.  Racing first calls
+// set the same value twice, which is harmless; nobody launches before the attribute is set on ITS device.
+struct AttrOnce { std::atomic<bool> done[32]; };
+template <class K>
+static hipError_t ensure_lds(AttrOnce& once, K kernel, size_t lds) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32)
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (once.done[dev].load(std::memory_order_acquire)) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) once.done[dev].store(true, std::memory_order_release);
+  return e;
+}
 template <int C, int CB, int KIND, int L, int NW, bool BC>
 static hipError_t launch_block_bc(const BlockArgs& a, int n_cu, hipStream_t s) {
   constexpr int NPOS = NW == 8 ? 128 / CB : 1;
   using G = Geo<NPOS, CB, 3, NW, NW == 8 ? kKMS : 2, NW == 8 ? kRingDepth : kRingDepth4>;
   constexpr size_t lds = G::ACT_BYTES + ring_bytes(CB, G::KMS, G::RD);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_block<C, CB, KIND, L, NW, BC>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static AttrOnce once;
+  if (hipError_t e = ensure_lds(once, k_block<C, CB, KIND, L, NW, BC>, lds); e != hipSuccess) return e;
   const int groups = (a.npos + NPOS - 1) / NPOS, cap = NW == 8 ? n_cu : 2 * n_cu;   // NW = 4: two workgroups per CU
   hipLaunchKernelGGL((k_block<C, CB, KIND, L, NW, BC>), dim3(groups < cap ? groups : cap), dim3(NW * 64), lds, s, a);
   return hipGetLastError();
@@ -1587,12 +1599,8 @@ static hipError_t launch_conv1x1_t(const Conv1x1Args& a, int n_cu, hipStream_t s
   constexpr int CP = (COUT >= 128 && CB == 128) ? 128 : 64;
   const int grid = conv_split_grid(a.npos, 128 / CB, (COUT + CP - 1) / CP, n_cu);
   constexpr size_t lds = G::ACT_BYTES + ring_bytes(CP);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = set_lds(k_conv1x1<CIN, COUT, PRE, EPI>, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static AttrOnce once;
+  if (hipError_t e = ensure_lds(once, k_conv1x1<CIN, COUT, PRE, EPI>, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((k_conv1x1<CIN, COUT, PRE, EPI>), dim3(grid), dim3(kWG), lds, s, a);
   return hipGetLastError();
 }
@@ -1625,12 +1633,8 @@ static hipError_t launch_lconv_nw(const LConvArgs& a, int n_cu, hipStream_t s) {
   const int grid = conv_split_grid(a.npos, NPOS, COUT / 64, NW == 8 ? n_cu : 2 * n_cu);   // NW = 4: two workgroups per CU
   constexpr size_t lds = G::ACT_BYTES + ring_bytes(64, G::KMS);
   static_assert(NW == 8 || 2 * lds <= 160 * 1024, "two workgroups per CU");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = set_lds(k_lconv<KW, CIN, COUT, PRE, ACT, RES, DUAL, NW>, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static AttrOnce once;
+  if (hipError_t e = ensure_lds(once, k_lconv<KW, CIN, COUT, PRE, ACT, RES, DUAL, NW>, lds); e != hipSuccess) return e;
   LConvArgs b = a;
   b.nms_total = a.nms_total * (kKMS / G::KMS);   // the host counts macro-steps of kKMS k16-steps
   static const bool turns = getenv("P3HIP_NO_PAIR_TURNS") == nullptr;
@@ -1668,14 +1672,12 @@ hipError_t launch_lconv(int kw, int cin, int cout, const LConvArgs& a, int grid,
 
 hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s) {
   constexpr size_t lds = 128 * kTtStride + ring_bytes(128) + (384 + 2 * 384) * 4;   // + epilogue parameters
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = set_lds(k_bdense<256>, lds);
-    if (e == hipSuccess) e = set_lds(k_bdense<128>, lds);
-    if (e == hipSuccess) e = set_lds(k_bdense<384>, lds);
-    if (e == hipSuccess) e = set_lds(k_bdense<192>, lds);
+  static AttrOnce once[4];
+  {
+    hipError_t e = C == 256 ? ensure_lds(once[0], k_bdense<256>, lds) : C == 128 ? ensure_lds(once[1], k_bdense<128>, lds)
+                 : C == 384 ? ensure_lds(once[2], k_bdense<384>, lds) : C == 192 ? ensure_lds(once[3], k_bdense<192>, lds)
+                 : hipErrorInvalidValue;
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   if (C == 192) {
     hipLaunchKernelGGL((k_bdense<192>), dim3(grid), dim3(kWG), lds, s, a);
@@ -1694,12 +1696,8 @@ hipError_t launch_bdense(int C, const BDenseArgs& a, int grid, hipStream_t s) {
 template <int V>
 static hipError_t launch_heads_t(const HeadsArgs& a, hipStream_t s) {
   using L = HeadsLds<32, V>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = set_lds(k_heads<32, V>, L::bytes);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static AttrOnce once;
+  if (hipError_t e = ensure_lds(once, k_heads<32, V>, L::bytes); e != hipSuccess) return e;
   const int grid = (a.npos + L::kGroups - 1) / L::kGroups;
   hipLaunchKernelGGL((k_heads<32, V>), dim3(grid), dim3(1024), L::bytes, s, a);
   return hipGetLastError();
@@ -1709,12 +1707,8 @@ template <int C, int V>
 static hipError_t launch_headsx_t(const HeadsArgs& a, int n_cu, hipStream_t s) {
   using X = HeadsxLds<C, 32, V>;
   static_assert(X::bytes <= 160 * 1024, "LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = set_lds(k_headsx<C, 32, V>, X::bytes);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static AttrOnce once;
+  if (hipError_t e = ensure_lds(once, k_headsx<C, 32, V>, X::bytes); e != hipSuccess) return e;
   const int groups = (a.npos + X::kGroups - 1) / X::kGroups;
   hipLaunchKernelGGL((k_headsx<C, 32, V>), dim3(groups < n_cu ? groups : n_cu), dim3(512), X::bytes, s, a);
   return hipGetLastError();

@@ -627,6 +627,7 @@ long g_last_bias_pruned = 0;
 double g_last_bias_adj = 0;
 int g_num_groups = 2;
 long g_step_limit = 0;   // > 0: the measured region ends after this many engine batches
+long g_step_rounds = 0;  // > 0: the measured region is this many ROUNDS (one batch of every group), anchored on one group
 int g_advance_limit = 0;   // > 0: untimed batches per group, at most, to play every game past its raw-policy opening
 long g_last_reuse_added = 0, g_last_examples = 0;
 }
@@ -664,6 +665,13 @@ void p3host_selfplay_set_groups(int n) { g_num_groups = n < 1 ? 1 : (n > 8 ? 8 :
 // > 0: subsequent p3host_selfplay_run calls measure exactly `batches` engine batches (bench.py's
 // --steps), whichever groups they fall in, instead of running for `seconds`; 0 restores the time limit.
 void p3host_selfplay_set_step_limit(long batches) { g_step_limit = batches > 0 ? batches : 0; }
+// > 0 (takes precedence over the step limit): subsequent runs measure `rounds` ROUNDS.  The window opens at the
+// completion of the warm-up batch of the group that finishes its warm-up last (the anchor) and closes at the
+// completion of the anchor's `rounds`-th batch after that: both ends sit at the same phase of the groups' cycle on
+// the GPU (the groups' forward passes complete in bursts, so a window between two arbitrary completions is off by
+// up to a burst), and every batch of any group that completes inside (t0, t1] is counted — in steady state one per
+// group and round.  bench.py's --steps; 0 = off.
+void p3host_selfplay_set_step_rounds(long rounds) { g_step_rounds = rounds > 0 ? rounds : 0; }
 // > 0: before the warm-up batches every group runs untimed batches until all its games have left
 // their raw-policy opening (up to 30 moves of one evaluation each, self_play_thread.cc:44,363-366),
 // at most `max_batches` of them, so that a short measured region is steady-state search; 0 = off.
@@ -711,6 +719,7 @@ struct p3host_selfplay_stats {
   // every completion weighs in instead of the first and the last (the groups' kernels interleave on the GPU, so
   // completions come in bursts and a short window's end points are +-1 batch); `seconds` is the window itself
   double seconds_fit;
+  long rounds;               // p3host_selfplay_set_step_rounds: the anchor group's batches inside the window (0 otherwise)
 };
 
 // Runs self-play for about `seconds` (after `warmup_batches` unmeasured batches per half).
@@ -799,14 +808,18 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   // groups those runs fall in; every run that completes inside the window is counted, with the game
   // counters of the host advance that loaded it.  The groups keep the GPU under the same load for the
   // whole window: a group leaves only when it sees the window closed.
-  const bool by_steps = g_step_limit > 0;
+  const long round_limit = g_step_rounds;
+  const bool by_rounds = round_limit > 0;
+  const bool by_steps = !by_rounds && g_step_limit > 0;
   const long step_limit = g_step_limit;
   const int advance_limit = g_advance_limit;
   std::mutex clock_mu;
   int phase = 0, groups_ready = 0;   // 0 advance + warm-up, 1 measuring, 2 over (guarded by clock_mu)
-  long counted = 0;
+  int anchor = -1;                   // by_rounds: the group whose completions open and close the window
+  long counted = 0, anchor_rounds = 0;
   std::chrono::steady_clock::time_point t0{}, t1{};
-  std::vector<double> done_at;   // completion instants of the counted batches, seconds since t0 (guarded by clock_mu)
+  // completion instants, seconds since t0 (guarded by clock_mu): of the counted batches, or (by_rounds) of the anchor's
+  std::vector<double> done_at;
   std::atomic<bool> failed{false};
   for (int h = 0; h < NG; ++h) {
     halves[h].driver = std::thread([&, h] {
@@ -827,10 +840,13 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
         bool over = false;
         {
           std::lock_guard<std::mutex> l(clock_mu);
-          if (phase == 1) {
+          // a run belongs to the window by its completion instant, not by when this thread got the lock: r1 is taken
+          // before the lock, so a run that completed before the window opened (or after it closed) can arrive here
+          // with the phase already changed
+          const bool inside = r1 > t0 && (phase == 1 || (phase == 2 && by_rounds && r1 <= t1));
+          if (inside && phase != 0) {
             ++H.measured_batches;
             ++counted;
-            done_at.push_back(std::chrono::duration<double>(r1 - t0).count());
             H.counted.moves += now.moves - prev.moves; H.counted.games += now.games - prev.games;
             H.counted.evals += now.evals - prev.evals; H.counted.black_wins += now.black_wins - prev.black_wins;
             H.counted.cache_hits += now.cache_hits - prev.cache_hits;
@@ -838,8 +854,17 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
             H.counted.bias_adj_abs_sum += now.bias_adj_abs_sum - prev.bias_adj_abs_sum;
             H.gpu_seconds += std::chrono::duration<double>(r1 - r0).count();
             H.host_seconds += last_host;
-            const bool enough = by_steps ? counted >= step_limit : std::chrono::duration<double>(r1 - t0).count() >= seconds;
-            if (enough || failed.load()) { phase = 2; t1 = r1; }
+            if (phase == 1) {
+              bool enough;
+              if (by_rounds) {
+                if (h == anchor) { ++anchor_rounds; done_at.push_back(std::chrono::duration<double>(r1 - t0).count()); }
+                enough = h == anchor && anchor_rounds >= round_limit;
+              } else {
+                done_at.push_back(std::chrono::duration<double>(r1 - t0).count());
+                enough = by_steps ? counted >= step_limit : std::chrono::duration<double>(r1 - t0).count() >= seconds;
+              }
+              if (enough) { phase = 2; t1 = r1; }
+            }
           } else if (phase == 0 && !ready) {
             bool in_opening = false;
             if (adv_left > 0) {
@@ -851,9 +876,10 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
             if (warm >= warmup_batches || failed.load()) {
               ready = true;
               for (auto& g : H.games) H.past_opening_at_start += g->past_opening();
-              if (++groups_ready == NG) { phase = failed.load() ? 2 : 1; t0 = t1 = r1; }
+              if (++groups_ready == NG) { phase = failed.load() ? 2 : 1; t0 = t1 = r1; anchor = h; }
             }
           }
+          if (phase == 1 && failed.load()) { phase = 2; t1 = r1; }
           over = phase == 2;
         }
         if (over) break;
@@ -894,8 +920,10 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     }
     out->seconds = std::chrono::duration<double>(t1 - t0).count();
     out->seconds_fit = out->seconds;
+    out->rounds = anchor_rounds;
     {
       // completion k (1-based) at done_at[k - 1], the window's opening = completion 0 at 0
+      // (by rounds: the anchor group's completions, one per round)
       const size_t n = done_at.size() + 1;
       if (n >= 4) {
         double sx = 0, sy = 0, sxx = 0, sxy = 0;

@@ -130,7 +130,7 @@ class SelfPlayStats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("positions", C.c_long), ("moves", C.c_long),
                 ("games", C.c_long), ("black_wins", C.c_long), ("batches", C.c_long),
                 ("gpu_seconds", C.c_double), ("host_seconds", C.c_double), ("cache_hits", C.c_long),
-                ("advance_batches", C.c_long), ("games_past_opening", C.c_long), ("seconds_fit", C.c_double)]
+                ("advance_batches", C.c_long), ("games_past_opening", C.c_long), ("seconds_fit", C.c_double), ("rounds", C.c_long)]
 
 
 def selfplay_run(weights: str | None, num_games: int, num_threads: int, seconds: float,
@@ -279,6 +279,16 @@ def set_step_limit(batches: int) -> None:
     L = lib()
     L.p3host_selfplay_set_step_limit.argtypes = [C.c_long]
     L.p3host_selfplay_set_step_limit(int(batches))
+
+
+def set_step_rounds(rounds: int) -> None:
+    """> 0: subsequent selfplay_run calls time `rounds` ROUNDS (bench.py --steps): the window opens and closes on
+    completions of the SAME game group (the one that finishes its warm-up last), `rounds` of its batches apart, and
+    counts every batch of any group that completes inside — one per group and round in steady state.  Takes
+    precedence over set_step_limit; 0 = off."""
+    L = lib()
+    L.p3host_selfplay_set_step_rounds.argtypes = [C.c_long]
+    L.p3host_selfplay_set_step_rounds(int(rounds))
 
 
 def last_run_counters():

@@ -471,6 +471,32 @@ def test_selfplay_host_over_the_cpu_engine_and_step_limit(built, weight_files):
     assert st.seconds > 0
 
 
+def test_round_anchored_window_counts_whole_rounds(built):
+    """bench.py's timed region (round 4): `rounds` ROUNDS, opened and closed by completions of the SAME group (the one
+    that finishes its warm-up last), so both ends sit at the same phase of the groups' cycle; every batch of any group
+    completing inside is counted with the positions its host advance loaded.  The anchor contributes exactly `rounds`
+    batches; the other groups, which nothing paces over the NullEvaluator, about as many each (on the GPU the
+    forward passes queue behind one another: exactly one per group and round)."""
+    from p3achygo_amd import host_api
+    host_api.set_groups(4)
+    host_api.set_step_rounds(6)
+    host_api.set_step_limit(3)           # ignored while rounds are set
+    try:
+        st = host_api.selfplay_run(None, num_games=64, num_threads=4, seconds=0.0, default_n=16, default_k=4,
+                                   selected_n=16, selected_k=4, warmup_batches=2, seed=5)
+        host_api.set_groups(1)           # one group: a round is a batch
+        solo = host_api.selfplay_run(None, num_games=16, num_threads=2, seconds=0.0, default_n=16, default_k=4,
+                                     selected_n=16, selected_k=4, warmup_batches=2, seed=5)
+    finally:
+        host_api.set_step_rounds(0)
+        host_api.set_step_limit(0)
+        host_api.set_groups(2)
+    assert st.rounds == 6 and 6 + 3 * 3 <= st.batches <= 6 + 3 * 12
+    assert st.positions == 16 * st.batches and st.seconds > 0
+    assert 0.5 * st.seconds < st.seconds_fit < 2.0 * st.seconds      # the anchor's 7 completion instants, fitted
+    assert solo.rounds == solo.batches == 6 and solo.positions == 6 * 16
+
+
 def test_advance_phase_plays_every_game_past_its_opening_before_the_timed_steps(built):
     """bench.py's untimed advance phase: a game samples its first moves from the raw policy,
     one evaluation per move, for up to 30 moves (self_play_thread.cc:44,363-366); with the advance limit set every

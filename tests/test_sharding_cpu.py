@@ -93,9 +93,15 @@ def test_bench_gpus_flag_starts_that_many_ranks(built):
     assert len(lines) == 1                                        # rank 0 alone prints
     b = json.loads(lines[0])
     assert a["n_gpus"] == 1 and b["n_gpus"] == 2
-    assert a["steps"] == b["steps"] == 7                          # exactly --steps, not rounded to whole rounds
-    assert a["engine_batches_completed"] == 7 and b["engine_batches_completed"] == 14   # K per rank, summed
-    assert b["positions"] == 2 * a["positions"] == 2 * 7 * 16     # weak scaling: per-rank work fixed
+    assert a["steps"] == b["steps"] == 7                          # --steps ROUNDS: one batch of each of the 3 groups
+    # the window opens and closes on completions of one group, 7 of its batches apart; the other two groups run on
+    # their own (over the NullEvaluator nothing paces them to each other — on the GPU the forward passes queue behind
+    # one another and every group completes one batch per round): about 7 completions each inside it
+    assert 7 + 2 * 4 <= a["engine_batches_completed"] <= 7 + 2 * 14
+    assert 2 * (7 + 2 * 4) <= b["engine_batches_completed"] <= 2 * (7 + 2 * 14)    # K rounds per rank, summed
+    assert a["positions"] == 16 * a["engine_batches_completed"]   # every batch full
+    assert b["positions"] == 16 * b["engine_batches_completed"]   # weak scaling: per-rank work fixed
+    assert a["ms_per_step"] == pytest.approx(a["seconds_timed"] / 7 * 1e3)
     assert b["games_past_opening"] == b["games_total"] == 2 * 3 * 16
     assert "NOT a measurement" in b["engine"] and b["roofline"] is None
     bad = subprocess.run(cmd + ["--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True,

@@ -120,6 +120,7 @@ if __name__ == "__main__":
     dump_nn("test_b5c256nbt_i2", 3, 25)
     dump_nn("test_b5c128btl1_i2", 3, 26)
     dump_nn("test_b5c256btl2_i2", 3, 27)
+    dump_nn("test_b10c256btl1_i2", 3, 28)
     # full-size BASELINE architectures: wide position sets; outputs stored as float32 (the
     # float64 results rounded once: 6e-8 relative, three orders below any tolerance)
     dump_nn("b8c128nbt", 8, 14, wide=True, store=np.float32)                  # C1

@@ -86,6 +86,11 @@ CONFIGS: Dict[str, NetConfig] = {
         # C = 256 btl with two inner layers and broadcast blocks 1 and 3: three one-block runs joined into ONE
         # k_block launch (conv_last head, fused dense tail on both sides of a run), V = 48 heads
         NetConfig("test_b5c256btl2_i2", 5, 256, 128, 32, 48, 2, 2, "btl"),
+        # ten blocks, every second one a broadcast block, the LAST block among them: five one-block runs — more than a
+        # joined launch takes (kMaxRuns = 4), so the first launch ends with a tail read from outside and the second
+        # begins with a head fed from outside (every run of such a launch stores to / loads from the SAME u buffer),
+        # and the trunk ends with a stand-alone conv_last
+        NetConfig("test_b10c256btl1_i2", 10, 256, 128, 32, 32, 2, 1, "btl"),
     ]
 }
 

@@ -41,7 +41,7 @@ PEAK_KL_TOL = 2e-4
 # the last six are full-size BASELINE architectures: C1 b8c128nbt, C2 b12c128btl3, C3/C4
 # b12c256btl3 (32 wide positions + a peaked-policy set), C5 b10c384nbt / b14c384btl3
 NETS = ["test_b3c128btl2", "test_b3c128nbt", "test_b3c256btl1", "test_b3c256nbt", "test_b3c384btl3", "test_b3c384nbt",
-        "test_b3c192classic", "test_b5c256nbt_i2", "test_b5c128btl1_i2", "test_b5c256btl2_i2", "b8c128nbt", "b12c128btl3", "b12c256btl3", "b12c256btl3_peaked", "b10c384nbt",
+        "test_b3c192classic", "test_b5c256nbt_i2", "test_b5c128btl1_i2", "test_b5c256btl2_i2", "test_b10c256btl1_i2", "b8c128nbt", "b12c128btl3", "b12c256btl3", "b12c256btl3_peaked", "b10c384nbt",
         "b14c384btl3"]
 PROB_KEYS = ("move_probs", "value_probs", "score_probs", "opt_move_probs")
 
@@ -313,14 +313,14 @@ sys.path.insert(0, %r)
 import numpy as np
 from p3achygo_amd import engine, features, netspec
 out = {}
-for name, batch in (("b12c256btl3", 300), ("test_b5c256nbt_i2", 5), ("test_b5c256btl2_i2", 37), ("b12c128btl3", 70), ("b8c128nbt", 600)):
+for name, batch in (("b12c256btl3", 300), ("test_b5c256nbt_i2", 5), ("test_b5c256btl2_i2", 37), ("test_b10c256btl1_i2", 11), ("test_b10c256btl1_i2", 300), ("b12c128btl3", 70), ("b8c128nbt", 600)):
     cfg = netspec.CONFIGS[name]
     path = os.path.join(tempfile.mkdtemp(), "n.p3w")
     netspec.save_p3w(path, cfg, netspec.generate_weights(cfg, randomize=True))
     pos = features.random_positions(batch, seed=5, n_games=9)
     eng = engine.HipEngine(path, batch)
     eng.load_all(pos); eng.RunInference()
-    out[name] = np.stack([eng.get_raw(i) for i in range(batch)])
+    out[name + (":%%d" %% batch if name in out else "")] = np.stack([eng.get_raw(i) for i in range(batch)])
     eng.close()
 np.savez(sys.argv[1], **out)
 """

@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT, load_golden
 
 SMALL = ["tiny", "test_b3c128btl2", "test_b3c128nbt", "test_b3c256btl1", "test_b3c256nbt", "test_b3c384btl3",
-         "test_b3c384nbt", "test_b3c192classic", "test_b5c256btl2_i2"]
+         "test_b3c384nbt", "test_b3c192classic", "test_b5c256btl2_i2", "test_b10c256btl1_i2"]
 
 
 def test_model_configs_match_reference_table():

@@ -177,6 +177,13 @@ double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
 /* P3HIP_FLAG_LAUNCH_GRAPH: 1 once the full-batch forward pass has been captured and is being replayed,
  * 0 before (or without the flag), -1 when the capture failed and the engine fell back to plain launches. */
 int p3hip_graph_state(const p3hip_engine* e);
+/* Diagnostics of the hand-scheduled block kernel k_blockw (engines created with P3HIP_BLOCKW_DIAG in the environment
+ * run its _diag twin, which stamps s_memtime at its section boundaries): copies up to n 64-bit stamps of the last
+ * forward pass, [workgroup 0..7][block 0..15][wave 0..3][24], to out.  Returns 0, or 1 when there are none. */
+int p3hip_blockw_stamps(p3hip_engine* e, unsigned long long* out, int n);
+/* Debugging aid: the residual stream x after the last forward pass (stopped early by P3HIP_DEBUG_STOP_BLOCK in the
+ * environment, if set), n_positions x C x 361 values in the device layout [pos][C / 8][361][8], as floats. */
+int p3hip_debug_x(p3hip_engine* e, float* out, int n_positions);
 /* Algorithmic FLOPs (2*MAC) of one position: total, and 3x3 trunk convs only. */
 void p3hip_flops_per_position(const p3hip_engine* e, double* total, double* conv3x3);
 

@@ -166,6 +166,17 @@ void pack_segment_3x3(std::vector<_Float16>& dst, const float* W, int cin_total,
               }
 }
 
+// k_blockw's weight granule (csrc/asm/blockw_gen.py): 64 output channels x 32 input channels of one tap as four
+// MFMA 16x16x32 A fragments, [cout tile ct][k chunk q][cout n][8] = W[tap][k0 + 8 q + e][cout0 + 16 ct + n]: lane
+// (n, q) of fragment ct reads its 16 bytes at ct * 1024 + lane * 16.
+void pack_granule(std::vector<_Float16>& dst, const float* W, int cin_total, int cout_total, int tap, int k0, int cout0) {
+  for (int ct = 0; ct < 4; ++ct)
+    for (int q = 0; q < 4; ++q)
+      for (int n = 0; n < 16; ++n)
+        for (int el = 0; el < 8; ++el)
+          dst.push_back((_Float16)W[((size_t)tap * cin_total + k0 + 8 * q + el) * cout_total + cout0 + 16 * ct + n]);
+}
+
 struct FoldedBN { size_t scale_off, shift_off; };
 
 // One conv launch of a layer-wise block (kind 4).  Regions: 0 = x; 1, 2 = the two C_b-channel
@@ -212,6 +223,13 @@ struct p3hip_engine {
   bool c128_wg8 = false;   // P3HIP_C128_WG8: C = 128 blocks as one 8-wave workgroup per CU (A/B timing)
   bool runs_contiguous = false;   // build_plan laid every run's streams back to back (joined launches possible)
   bool bcast_fuse = true;  // P3HIP_NO_BFUSE clears it: broadcast 1x1 convs as their own launches (A/B, tests)
+  // k_blockw (csrc/asm/blockw_gen.py): the runs of C = 256 btl blocks by the hand-scheduled one-wave-per-SIMD kernel
+  bool blockw = false;
+  struct BlockwRun { size_t first; int nblk; size_t stream_off, prm_off; };
+  std::vector<BlockwRun> bw_runs;
+  hipModule_t bw_mod = nullptr;
+  hipFunction_t bw_fn = nullptr;
+  unsigned long long* d_bw_stamps = nullptr;   // P3HIP_BLOCKW_DIAG: s_memtime stamps of the _diag kernel
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // P3HIP_FLAG_LAUNCH_GRAPH: the forward pass over the full static batch, captured once (trt_engine.cc:260-303)
@@ -341,6 +359,12 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
     e->init_stream_off = add_stream(ar, s, e->init_nms, CPI);
     e->game_w_off = ar.add(wf.get("init_game.w", (size_t)8 * C).data, 8 * C * 4);
     e->game_b_off = ar.add(wf.get("init_game.b", (size_t)C).data, C * 4);
+  }
+  // k_blockw serves C = 256 / C_b = 128 btl trunks; the broadcast blocks then run as their own launches
+  {
+    static const bool want_blockw = getenv("P3HIP_BLOCKW") != nullptr && atoi(getenv("P3HIP_BLOCKW")) != 0;
+    e->blockw = want_blockw && C == 256 && Cb == 128 && wf.btype == 0 && wf.inner >= 1 && wf.inner <= 3;
+    if (e->blockw) e->bcast_fuse = false;
   }
   bool have_xa = false;   // layer-wise path: u holds mish(bn0(x)) of the next block
   // The weight streams of consecutive fused blocks go into the arena back to back, after the
@@ -527,6 +551,60 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
   flush_run();
   for (auto& f : layout) f();
   e->runs_contiguous = true;
+  if (e->blockw) {
+    // Per run of consecutive btl blocks: the weight stream in the order k_blockw consumes it and the parameter table
+    // (folded BN rows times log2(e): the kernel's exp2-based mish takes them pre-multiplied, as bn_mish8_l2 does).
+    //   block stream: reduce: k32 step s = 0..7 (x channels 32 s ..), sets A (couts 0..63), B (64..127)
+    //                 layer j: phases (A, lo) (B, lo) (A, hi) (B, hi), each (ky, q32, kx) over its 64 input channels
+    //                 expand: output quarters 0..3, k32 steps 0..3
+    //   block table:  bn0 scale[256] shift[256] | j = 1 .. L + 1: scale[128] shift[128]
+    const int L = wf.inner;
+    for (size_t bi = 0; bi < e->blocks.size();) {
+      if (e->blocks[bi].kind != 0) { ++bi; continue; }
+      size_t n = 1;
+      while (bi + n < e->blocks.size() && e->blocks[bi + n].kind == 0) ++n;
+      std::vector<_Float16> ws;
+      std::vector<float> prm;
+      for (size_t b = bi; b < bi + n; ++b) {
+        // block index in the weight file = plan index (one BlockPlan per trunk block)
+        const std::string p = "blocks." + std::to_string(b);
+        auto W = [&](int j, int kw, int cin, int cout) {
+          return wf.get(p + ".conv" + std::to_string(j) + ".w", (size_t)kw * kw * cin * cout).data;
+        };
+        const float* w0 = W(0, 1, C, Cb);
+        for (int st = 0; st < 8; ++st)
+          for (int s0 = 0; s0 < 128; s0 += 64) pack_granule(ws, w0, C, Cb, 0, 32 * st, s0);
+        for (int j = 1; j <= L; ++j) {
+          const float* wj = W(j, 3, Cb, Cb);
+          for (int ph = 0; ph < 4; ++ph) {
+            const int s0 = (ph & 1) * 64, half = ph >> 1;
+            for (int ky = 0; ky < 3; ++ky)
+              for (int q = 0; q < 2; ++q)
+                for (int kx = 0; kx < 3; ++kx) pack_granule(ws, wj, Cb, Cb, ky * 3 + kx, 64 * half + 32 * q, s0);
+          }
+        }
+        const float* we = W(L + 1, 1, Cb, C);
+        for (int qo = 0; qo < 4; ++qo)
+          for (int c = 0; c < 4; ++c) pack_granule(ws, we, Cb, C, 0, 32 * c, 64 * qo);
+        const BlockPlan& bp = e->blocks[b];
+        for (int j = 0; j <= L + 1; ++j) {
+          const size_t nch = j == 0 ? C : Cb;
+          const float* sc = reinterpret_cast<const float*>(ar.host.data() + bp.bn[j].scale_off);
+          const float* sh = reinterpret_cast<const float*>(ar.host.data() + bp.bn[j].shift_off);
+          for (size_t c = 0; c < nch; ++c) prm.push_back(sc[c] * 1.4426950408889634f);
+          for (size_t c = 0; c < nch; ++c) prm.push_back(sh[c] * 1.4426950408889634f);
+        }
+      }
+      p3hip_engine::BlockwRun run;
+      run.first = bi;
+      run.nblk = (int)n;
+      run.stream_off = ar.add(ws.data(), ws.size() * 2);
+      run.prm_off = ar.add(prm.data(), prm.size() * 4);
+      if (ws.size() * 2 != n * (size_t)(32 + 72 * L) * 4096 || prm.size() != n * (size_t)(512 + 256 * (L + 1))) ar.bad_stream = true;
+      e->bw_runs.push_back(run);
+      bi += n;
+    }
+  }
   // heads: conv_p | conv_g | value.conv  -> [C][96]
   {
     std::vector<float> w((size_t)C * 96);
@@ -767,6 +845,47 @@ int fused_run(const p3hip_engine* e, size_t first) {
   return n;
 }
 
+// k_blockw: the code object assembled from csrc/asm/blockw_gen.py's output rides in the library as a blob
+// (blockw_blob.S); one module per engine (modules are per device).  Kernel arguments: csrc/asm/blockw_gen.py.
+extern "C" const unsigned char p3_blockw_hsaco[];
+extern "C" const unsigned char p3_blockw_hsaco_end[];
+struct BlockwArgs {
+  const void* x; const void* ws; const void* prm;
+  int npos, nblk, nwg, pad;
+  void* stamps;
+  unsigned long long pad2[2];
+};
+static_assert(sizeof(BlockwArgs) == 64, "kernarg layout of k_blockw");
+
+bool load_blockw(p3hip_engine* e) {
+  if (e->bw_fn) return true;
+  static const bool diag = getenv("P3HIP_BLOCKW_DIAG") != nullptr;
+  if (!e->check(hipModuleLoadData(&e->bw_mod, p3_blockw_hsaco), "hipModuleLoadData k_blockw")) return false;
+  const std::string name = "k_blockw_L" + std::to_string(e->wf.inner) + (diag ? "_diag" : "");
+  if (!e->check(hipModuleGetFunction(&e->bw_fn, e->bw_mod, name.c_str()), "hipModuleGetFunction k_blockw")) return false;
+  if (diag) {
+    constexpr size_t bytes = 8 * 16 * 4 * 24 * 8;   // [workgroup 0..7][block][wave][stamp]
+    if (!e->check(hipMalloc((void**)&e->d_bw_stamps, bytes), "hipMalloc stamps") ||
+        !e->check(hipMemsetAsync(e->d_bw_stamps, 0, bytes, e->stream), "hipMemset stamps")) return false;
+  }
+  return true;
+}
+
+bool launch_blockw(p3hip_engine* e, const p3hip_engine::BlockwRun& run, int npos) {
+  if (!load_blockw(e)) return false;
+  BlockwArgs a{};
+  a.x = e->d_x;
+  a.ws = e->d_arena + run.stream_off;
+  a.prm = e->d_arena + run.prm_off;
+  a.npos = npos;
+  a.nblk = run.nblk;
+  a.nwg = npos < e->n_cu ? npos : e->n_cu;
+  a.stamps = e->d_bw_stamps;
+  size_t size = sizeof a;
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return e->check(hipModuleLaunchKernel(e->bw_fn, a.nwg, 1, 1, 256, 1, 1, 0, e->stream, nullptr, cfg), "launch k_blockw");
+}
+
 // Enqueues the whole forward pass for `npos` dense positions already in d_feats.
 bool enqueue_forward(p3hip_engine* e, int npos) {
   const WeightFile& wf = e->wf;
@@ -783,7 +902,10 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
 #ifdef P3_DIAG
   e->launch_index = 0;
 #endif
+  // debugging aid (tools/gpu_blockw_ab.py xdiff): stop the forward pass in front of plan block P3HIP_DEBUG_STOP_BLOCK
+  static const int stop_block = getenv("P3HIP_DEBUG_STOP_BLOCK") ? atoi(getenv("P3HIP_DEBUG_STOP_BLOCK")) : -1;
   for (size_t bi = 0; bi < e->blocks.size(); ++bi) {
+    if (stop_block >= 0 && (int)bi >= stop_block) return true;
     const BlockPlan& bp = e->blocks[bi];
     if (bp.kind == 3) {
       p3::Conv1x1Args c0{};
@@ -818,6 +940,15 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
         if (!e->check(p3::launch_lconv(lp.kw, lp.cin, lp.cout, a, e->n_cu, s), "launch k_lconv")) return false;
         if (timed) hipEventRecord(e->blk_ev[2 * e->timed_blocks++ + 1], s);
       }
+    } else if (e->blockw && bp.kind == 0) {
+      const p3hip_engine::BlockwRun* run = nullptr;
+      for (const auto& r : e->bw_runs) if (r.first == bi) run = &r;
+      if (!run) { e->err = "internal error: no k_blockw run starts at this block"; return false; }
+      const bool timed = e->time_blocks && 2 * e->timed_blocks + 1 < (int)e->blk_ev.size();
+      if (timed) hipEventRecord(e->blk_ev[2 * e->timed_blocks], s);
+      if (!launch_blockw(e, *run, npos)) return false;
+      if (timed) hipEventRecord(e->blk_ev[2 * e->timed_blocks++ + 1], s);
+      bi += run->nblk - 1;
     } else {
       int run = fused_run(e, bi);
       p3::BlockArgs a;
@@ -989,6 +1120,8 @@ void p3hip_destroy(p3hip_engine* e) {
   if (e->stream) hipStreamSynchronize(e->stream);
   hipFree(e->d_arena); hipFree(e->d_feats); hipFree(e->d_x); hipFree(e->d_t); hipFree(e->d_u); hipFree(e->d_s);
   hipFree(e->d_hp); hipFree(e->d_out);
+  hipFree(e->d_bw_stamps);
+  if (e->bw_mod) hipModuleUnload(e->bw_mod);
   {
     auto& c = e->cache;
     hipFree(c.d_tkeys); hipFree(c.d_tmeta); hipFree(c.d_tvals); hipFree(c.d_keys); hipFree(c.d_hit); hipFree(c.d_victim);
@@ -1357,8 +1490,28 @@ double p3hip_time_trunk_kernel(p3hip_engine* e, int n_positions, int iters,
     *flops_per_launch = 2.0 * n_positions * kNLoc *
                         (blocks_per_launch * (n3 * 9.0 * wf.Cb * wf.Cb + 2.0 * wf.C * wf.Cb) + bconv_per_launch * (double)wf.C * wf.C +
                          dense_per_launch * (double)wf.C * kNLoc);
-  if (kernel_name) *kernel_name = p3::block_kernel_name(wf.C, bp->kind, wf.inner);
+  if (kernel_name) *kernel_name = e->blockw ? (wf.inner == 3 ? "k_blockw_L3" : wf.inner == 2 ? "k_blockw_L2" : "k_blockw_L1")
+                                            : p3::block_kernel_name(wf.C, bp->kind, wf.inner);
   return launches ? total_ms / launches : -1.0;
+}
+
+// debugging aid: the residual stream x of the last forward pass, n_positions x C x 361 fp16 in the device layout
+// [pos][C / 8][361][8], as floats
+int p3hip_debug_x(p3hip_engine* e, float* out, int n_positions) {
+  if (!e->bind() || n_positions < 1 || n_positions > e->batch) return 1;
+  const size_t n = (size_t)n_positions * e->wf.C * kNLoc;
+  std::vector<_Float16> h(n);
+  hipStreamSynchronize(e->stream);
+  if (hipMemcpy(h.data(), e->d_x, n * 2, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+  for (size_t i = 0; i < n; ++i) out[i] = (float)h[i];
+  return 0;
+}
+
+int p3hip_blockw_stamps(p3hip_engine* e, unsigned long long* out, int n) {
+  if (!e->bind() || !e->d_bw_stamps) return 1;
+  constexpr int total = 8 * 16 * 4 * 24;
+  hipStreamSynchronize(e->stream);
+  return hipMemcpy(out, e->d_bw_stamps, (size_t)(n < total ? n : total) * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
 }
 
 #ifdef P3_DIAG

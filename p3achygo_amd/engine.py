@@ -29,6 +29,7 @@ EXPORTS = [
     "p3hip_last_error", "p3hip_forward_resident", "p3hip_upload", "p3hip_sync", "p3hip_get_raw",
     "p3hip_time_trunk_kernel", "p3hip_flops_per_position", "p3hip_graph_state",
     "p3hip_cache_enable", "p3hip_load_slot_keyed", "p3hip_get_slot_keyed", "p3hip_cache_stats",
+    "p3hip_blockw_stamps", "p3hip_debug_x",
 ]
 
 FLAG_RUN_ALL_SLOTS = 2
@@ -204,6 +205,21 @@ class HipEngine:
         if ms < 0:
             raise EngineError("time_trunk_kernel: " + self._L.p3hip_last_error(self._h).decode())
         return ms, fl.value, (name.value or b"").decode()
+
+    def debug_x(self, n: int, channels: int) -> np.ndarray:
+        """residual stream after the last forward pass as [n][channels][361] floats"""
+        out = np.zeros(n * channels * 361, np.float32)
+        self._L.p3hip_debug_x.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self._ck(self._L.p3hip_debug_x(self._h, out.ctypes.data, n), "debug_x")
+        return out.reshape(n, channels // 8, 361, 8).transpose(0, 1, 3, 2).reshape(n, channels, 361)
+
+    def blockw_stamps(self) -> np.ndarray:
+        """s_memtime stamps of k_blockw's _diag twin (P3HIP_BLOCKW=1 P3HIP_BLOCKW_DIAG=1): [wg 8][block 16][wave 4][24]"""
+        out = np.zeros(8 * 16 * 4 * 24, np.uint64)
+        self._L.p3hip_blockw_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        if self._L.p3hip_blockw_stamps(self._h, out.ctypes.data, out.size) != 0:
+            raise EngineError("no k_blockw stamps (engine not created with P3HIP_BLOCKW_DIAG)")
+        return out.reshape(8, 16, 4, 24)
 
     def graph_state(self) -> int:
         """P3HIP_FLAG_LAUNCH_GRAPH: 1 replaying the captured forward pass, 0 not (yet), -1 capture failed."""

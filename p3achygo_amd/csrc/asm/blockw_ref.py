@@ -50,22 +50,30 @@ def block_ref(x16, W, bn, L):
     return (y.astype(np.float64) + x16.astype(np.float64)).astype(np.float32).astype(np.float16)
 
 
-def granule(Wf, tap, k0, cout0):
-    """Wf [taps][cin][cout] -> 2048 fp16: [ct][q][n][8] = W[tap][k0 + 8 q + e][cout0 + 16 ct + n]"""
-    out = np.zeros((4, 4, 16, 8), np.float16)
-    for ct in range(4):
-        for q in range(4):
-            out[ct, q] = Wf[tap, k0 + 8 * q:k0 + 8 * q + 8, cout0 + 16 * ct:cout0 + 16 * ct + 16].T
+def granule(Wf, tap, k0, cout0, scale=None):
+    """Wf [taps][cin][cout] -> 2048 fp16: [k16 half j][cout tile c][h][n][8] = W[tap][k0 + 16 j + 8 h + e][cout0 + 32 c + n]
+    (times scale[cout]: the folded BN scale of the layer that follows, times log2 e), rounded to fp16 once"""
+    out = np.zeros((2, 2, 2, 32, 8), np.float16)
+    for j in range(2):
+        for c in range(2):
+            for h in range(2):
+                k = k0 + 16 * j + 8 * h
+                blk = Wf[tap, k:k + 8, cout0 + 32 * c:cout0 + 32 * c + 32].astype(np.float32)      # [8][32]
+                if scale is not None:
+                    blk = blk * scale[cout0 + 32 * c:cout0 + 32 * c + 32][None, :]
+                out[j, c, h] = blk.T.astype(np.float16)
     return out.reshape(-1)
 
 
 def pack_block(W, bn, L):
     """-> (weight stream fp16, parameter floats) of one block, engine.cpp build_plan's order"""
     ws = []
+    sc = lambda j: (bn[j][0] * LOG2E).astype(np.float32)      # noqa: E731
     w0 = W[0].reshape(1, 256, 128)
-    for st in range(8):
+    for half in range(2):                     # x quarters (0, 1) then (2, 3); inside: set A's four granules, then set B's
         for s0 in (0, 64):
-            ws.append(granule(w0, 0, 32 * st, s0))
+            for st in range(4):
+                ws.append(granule(w0, 0, 128 * half + 32 * st, s0, sc(1)))
     for j in range(1, L + 1):
         wj = W[j].reshape(9, 128, 128)
         for ph in range(4):
@@ -73,14 +81,13 @@ def pack_block(W, bn, L):
             for ky in range(3):
                 for q in range(2):
                     for kx in range(3):
-                        ws.append(granule(wj, ky * 3 + kx, 64 * half + 32 * q, s0))
+                        ws.append(granule(wj, ky * 3 + kx, 64 * half + 32 * q, s0, sc(j + 1)))
     we = W[L + 1].reshape(1, 128, 256)
     for qo in range(4):
         for c in range(4):
             ws.append(granule(we, 0, 32 * c, 64 * qo))
-    prm = []
-    for j in range(L + 2):
-        prm.append((bn[j][0] * LOG2E).astype(np.float32))
+    prm = [(bn[0][0] * LOG2E).astype(np.float32), (bn[0][1] * LOG2E).astype(np.float32)]
+    for j in range(1, L + 2):
         prm.append((bn[j][1] * LOG2E).astype(np.float32))
     return np.concatenate(ws), np.concatenate(prm)
 

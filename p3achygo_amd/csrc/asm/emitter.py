@@ -72,7 +72,7 @@ def _need_gap(p, c, raw):
     if p.kind == "mfma":
         if c.kind == "mfma":
             return 0              # accumulate chain on the same registers: interlocked
-        return 16                 # 8-pass XDL result -> any other reader / writer
+        return 20 if p.note == "mfma32" else 16   # 16- / 8-pass XDL result -> any other reader / writer
     if p.kind == "trans":
         return 2
     if p.kind in ("valu", "perm"):
@@ -121,6 +121,11 @@ class Emitter:
             n -= k
 
     # ---- waits -----------------------------------------------------------------------------
+    def prewait(self, regs_):
+        """one wait for everything in `regs_` that is still in flight (a K step's fragments at its start: each
+        s_waitcnt costs an issue slot, so one per step instead of one per fragment)"""
+        self.wait_regs(regs(*regs_))
+
     def _wait_lgkm(self, n):
         self.lines.append(f"\ts_waitcnt lgkmcnt({n})")
         self.stats["wait_lgkm"] += 1
@@ -207,7 +212,7 @@ class Emitter:
             self.vm.append((set(ins.dst), ins.note))
 
     # ---- weaving ----------------------------------------------------------------------------
-    def weave(self, main, budget=8, mfma_cost=8):
+    def weave(self, main, budget=24, mfma_cost=8):
         """main: list of items; an item is an Ins, a Bundle, or a control tuple:
              ("start", name, [filler items])   the filler stream `name` may be issued from here on
              ("flush", name)                   everything left of stream `name` is issued here
@@ -230,7 +235,9 @@ class Emitter:
                 continue
             self.emit(it)
             if isinstance(it, Ins) and it.kind == "mfma":
-                credit = min(credit, 0) + budget
+                # what the main stream spent since the last MFMA comes out of this gap, and a bounded part of an older debt
+                # (an exposed stretch of main-stream VALU work must not starve the fillers of the K loop behind it)
+                credit = max(min(credit, 0), -2 * budget) + budget
                 while pending and credit > 0:
                     name, q = pending[0]
                     if not q:
@@ -241,8 +248,10 @@ class Emitter:
                         break
                     self.emit(q.popleft())
                     credit -= nxt.cost
-            elif isinstance(it, Ins) and it.kind in ("ds_r", "ds_w", "dma"):
-                credit -= 2
+            elif isinstance(it, Ins):
+                credit -= it.cost
+            elif isinstance(it, Bundle):
+                credit -= it.cost
         for name, q in pending:
             if q:
                 raise RuntimeError(f"filler stream {name} was never flushed ({len(q)} items left)")
@@ -258,9 +267,24 @@ def mfma(acc_out, a, b, acc_in):
     return Ins(f"v_mfma_f32_16x16x32_f16 {rtxt(acc_out)}, {rtxt(a)}, {rtxt(b)}, {c}", "mfma", [acc_out], src, 8)
 
 
+def mfma32(acc_out, a, b, acc_in):
+    """v_mfma_f32_32x32x16_f16: 16 passes (32 cycles on the matrix pipe), 8 of them hold the wave's issue"""
+    c = rtxt(acc_in) if isinstance(acc_in, tuple) else "0"
+    src = [a, b] + ([acc_in] if isinstance(acc_in, tuple) else [])
+    return Ins(f"v_mfma_f32_32x32x16_f16 {rtxt(acc_out)}, {rtxt(a)}, {rtxt(b)}, {c}", "mfma", [acc_out], src, 8, "mfma32")
+
+
+def permswap32(x, y):
+    return Ins(f"v_permlane32_swap_b32 {rtxt(x)}, {rtxt(y)}", "perm", [x, y], [x, y], 4)
+
+
+def cvt_pk(dst, a, b):
+    return Ins(f"v_cvt_pk_f16_f32 {rtxt(dst)}, {rtxt(a)}, {rtxt(b)}", "valu", [dst], [a, b], 4)
+
+
 def ds_read128(dst, addr, off):
     assert 0 <= off < 65536, off
-    return Ins(f"ds_read_b128 {rtxt(dst)}, {rtxt(addr)} offset:{off}", "ds_r", [dst], [addr], 2)
+    return Ins(f"ds_read_b128 {rtxt(dst)}, {rtxt(addr)} offset:{off}", "ds_r", [dst], [addr], 4)
 
 
 def ds_write128(addr, data, off):
@@ -297,10 +321,10 @@ def permswap16(x, y):
     return Ins(f"v_permlane16_swap_b32 {rtxt(x)}, {rtxt(y)}", "perm", [x, y], [x, y], 4)
 
 
-def salu(op, dst, *src, cost=1):
+def salu(op, dst, *src, cost=4):
     ops = ", ".join(rtxt(x) for x in (dst,) + src)
     return Ins(f"{op} {ops}", "salu", [dst] if isinstance(dst, tuple) else [], list(src), cost)
 
 
-def misc(text, cost=1):
+def misc(text, cost=4):
     return Ins(text, "misc", [], [], cost)

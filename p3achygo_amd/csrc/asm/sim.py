@@ -520,6 +520,50 @@ class Sim:
             out[i] = (D[4 * q + i, n] + C[i].astype(np.float64)).astype(np.float32)
         w.v[db:db + 4] = out.view(np.uint32)
 
+    def op_v_mfma_f32_32x32x16_f16(self, w, o, mods):
+        def frag(op):     # [lane][8] halves
+            base = op[1] + (256 if op[0] == "a" else 0)
+            return w.v[base:base + 4].T.copy().view(np.float16).reshape(NLANE, 8).astype(np.float64)
+        fa, fb = frag(o[1]), frag(o[2])
+        lane = np.arange(NLANE)
+        n, h = lane & 31, lane >> 5
+        Am = np.zeros((32, 16))
+        Bm = np.zeros((16, 32))
+        for l in range(NLANE):
+            Am[n[l], 8 * h[l]:8 * h[l] + 8] = fa[l]
+            Bm[8 * h[l]:8 * h[l] + 8, n[l]] = fb[l]
+        D = Am @ Bm
+        if o[3][0] in ("a", "v"):
+            cb = o[3][1] + (256 if o[3][0] == "a" else 0)
+            C = _f32(w.v[cb:cb + 16].reshape(-1)).reshape(16, NLANE)
+        else:
+            C = np.zeros((16, NLANE), np.float32)
+        db = o[0][1] + (256 if o[0][0] == "a" else 0)
+        out = np.zeros((16, NLANE), np.float32)
+        for i in range(16):
+            row = 8 * (i >> 2) + 4 * h + (i & 3)
+            out[i] = (D[row, n] + C[i].astype(np.float64)).astype(np.float32)
+        w.v[db:db + 16] = out.view(np.uint32)
+
+    def op_v_permlane32_swap_b32(self, w, o, mods):
+        x = self._v(w, o[0]).astype(np.uint32).copy()
+        y = self._v(w, o[1]).astype(np.uint32).copy()
+        nx, ny = x.copy(), y.copy()
+        nx[32:64] = y[0:32]
+        ny[0:32] = x[32:64]
+        full = np.ones(NLANE, bool)
+        self.wr32(w, o[0], nx, mask=full)
+        self.wr32(w, o[1], ny, mask=full)
+
+    def op_v_cvt_pk_f16_f32(self, w, o, mods):
+        with np.errstate(over="ignore"):
+            lo = self._fl(w, o[1]).astype(np.float16).view(np.uint16).astype(np.uint32)
+            hi = self._fl(w, o[2]).astype(np.float16).view(np.uint16).astype(np.uint32)
+        self.wr32(w, o[0], lo | (hi << 16))
+
+    def op_v_mul_f32(self, w, o, mods):
+        self.wr32(w, o[0], _u32((self._fl(w, o[1]).astype(np.float64) * self._fl(w, o[2]).astype(np.float64)).astype(np.float32)))
+
     # ---- LDS / memory ---------------------------------------------------------------------------
     def op_ds_read_b128(self, w, o, mods):
         addr = self._v(w, o[1]).astype(np.int64) + mods.get("offset", 0)

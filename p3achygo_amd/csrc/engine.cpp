@@ -167,14 +167,21 @@ void pack_segment_3x3(std::vector<_Float16>& dst, const float* W, int cin_total,
 }
 
 // k_blockw's weight granule (csrc/asm/blockw_gen.py): 64 output channels x 32 input channels of one tap as four
-// MFMA 16x16x32 A fragments, [cout tile ct][k chunk q][cout n][8] = W[tap][k0 + 8 q + e][cout0 + 16 ct + n]: lane
-// (n, q) of fragment ct reads its 16 bytes at ct * 1024 + lane * 16.
-void pack_granule(std::vector<_Float16>& dst, const float* W, int cin_total, int cout_total, int tap, int k0, int cout0) {
-  for (int ct = 0; ct < 4; ++ct)
-    for (int q = 0; q < 4; ++q)
-      for (int n = 0; n < 16; ++n)
-        for (int el = 0; el < 8; ++el)
-          dst.push_back((_Float16)W[((size_t)tap * cin_total + k0 + 8 * q + el) * cout_total + cout0 + 16 * ct + n]);
+// MFMA 32x32x16 A fragments, [k16 half j][cout tile c][h][n][8] = W[tap][k0 + 16 j + 8 h + e][cout0 + 32 c + n]: lane
+// (n, h) of fragment (j, c) reads its 16 bytes at (2 j + c) * 1024 + lane * 16.  scale (may be null): the folded BN scale
+// of the layer that FOLLOWS the conv, times log2(e), per output channel — multiplied in before the one fp16 rounding.
+void pack_granule(std::vector<_Float16>& dst, const float* W, int cin_total, int cout_total, int tap, int k0, int cout0,
+                  const float* scale) {
+  for (int j = 0; j < 2; ++j)
+    for (int c = 0; c < 2; ++c)
+      for (int h = 0; h < 2; ++h)
+        for (int n = 0; n < 32; ++n)
+          for (int el = 0; el < 8; ++el) {
+            const int co = cout0 + 32 * c + n;
+            float v = W[((size_t)tap * cin_total + k0 + 16 * j + 8 * h + el) * cout_total + co];
+            if (scale) v *= scale[co];
+            dst.push_back((_Float16)v);
+          }
 }
 
 struct FoldedBN { size_t scale_off, shift_off; };
@@ -552,13 +559,16 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
   for (auto& f : layout) f();
   e->runs_contiguous = true;
   if (e->blockw) {
-    // Per run of consecutive btl blocks: the weight stream in the order k_blockw consumes it and the parameter table
-    // (folded BN rows times log2(e): the kernel's exp2-based mish takes them pre-multiplied, as bn_mish8_l2 does).
-    //   block stream: reduce: k32 step s = 0..7 (x channels 32 s ..), sets A (couts 0..63), B (64..127)
+    // Per run of consecutive btl blocks: the weight stream in the order k_blockw consumes it and the parameter table.
+    // The BN in front of a conv's consumer rides in the conv: its folded scale times log2(e) is multiplied into the fp16
+    // weights, its shift times log2(e) is the accumulators' initial value (the kernel's exp2-based mish takes
+    // log2(e) * y, as bn_mish8_l2 does).
+    //   block stream: reduce: x halves (quarters 0, 1 / 2, 3); in a half set A's four k32 granules, then set B's
     //                 layer j: phases (A, lo) (B, lo) (A, hi) (B, hi), each (ky, q32, kx) over its 64 input channels
-    //                 expand: output quarters 0..3, k32 steps 0..3
-    //   block table:  bn0 scale[256] shift[256] | j = 1 .. L + 1: scale[128] shift[128]
+    //                 expand: output quarters 0..3, k32 steps 0..3 (unscaled: the residual add follows)
+    //   block table:  bn0 scale[256] shift[256] (times log2 e) | conv j = 0 .. L: shift[128] of bn j + 1 (times log2 e)
     const int L = wf.inner;
+    const float kLog2e = 1.4426950408889634f;
     for (size_t bi = 0; bi < e->blocks.size();) {
       if (e->blocks[bi].kind != 0) { ++bi; continue; }
       size_t n = 1;
@@ -571,28 +581,38 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
         auto W = [&](int j, int kw, int cin, int cout) {
           return wf.get(p + ".conv" + std::to_string(j) + ".w", (size_t)kw * kw * cin * cout).data;
         };
+        const BlockPlan& bp = e->blocks[b];
+        auto bn_row = [&](int j, bool shift) {
+          const float* v = reinterpret_cast<const float*>(ar.host.data() + (shift ? bp.bn[j].shift_off : bp.bn[j].scale_off));
+          std::vector<float> r((size_t)(j == 0 ? C : Cb));
+          for (size_t c = 0; c < r.size(); ++c) r[c] = v[c] * kLog2e;
+          return r;
+        };
         const float* w0 = W(0, 1, C, Cb);
-        for (int st = 0; st < 8; ++st)
-          for (int s0 = 0; s0 < 128; s0 += 64) pack_granule(ws, w0, C, Cb, 0, 32 * st, s0);
+        const std::vector<float> s1 = bn_row(1, false);
+        for (int half = 0; half < 2; ++half)
+          for (int s0 = 0; s0 < 128; s0 += 64)
+            for (int st = 0; st < 4; ++st) pack_granule(ws, w0, C, Cb, 0, 128 * half + 32 * st, s0, s1.data());
         for (int j = 1; j <= L; ++j) {
           const float* wj = W(j, 3, Cb, Cb);
+          const std::vector<float> sj = bn_row(j + 1, false);
           for (int ph = 0; ph < 4; ++ph) {
             const int s0 = (ph & 1) * 64, half = ph >> 1;
             for (int ky = 0; ky < 3; ++ky)
               for (int q = 0; q < 2; ++q)
-                for (int kx = 0; kx < 3; ++kx) pack_granule(ws, wj, Cb, Cb, ky * 3 + kx, 64 * half + 32 * q, s0);
+                for (int kx = 0; kx < 3; ++kx) pack_granule(ws, wj, Cb, Cb, ky * 3 + kx, 64 * half + 32 * q, s0, sj.data());
           }
         }
         const float* we = W(L + 1, 1, Cb, C);
         for (int qo = 0; qo < 4; ++qo)
-          for (int c = 0; c < 4; ++c) pack_granule(ws, we, Cb, C, 0, 32 * c, 64 * qo);
-        const BlockPlan& bp = e->blocks[b];
-        for (int j = 0; j <= L + 1; ++j) {
-          const size_t nch = j == 0 ? C : Cb;
-          const float* sc = reinterpret_cast<const float*>(ar.host.data() + bp.bn[j].scale_off);
-          const float* sh = reinterpret_cast<const float*>(ar.host.data() + bp.bn[j].shift_off);
-          for (size_t c = 0; c < nch; ++c) prm.push_back(sc[c] * 1.4426950408889634f);
-          for (size_t c = 0; c < nch; ++c) prm.push_back(sh[c] * 1.4426950408889634f);
+          for (int c = 0; c < 4; ++c) pack_granule(ws, we, Cb, C, 0, 32 * c, 64 * qo, nullptr);
+        for (int sh = 0; sh < 2; ++sh) {
+          const std::vector<float> r = bn_row(0, sh == 1);
+          prm.insert(prm.end(), r.begin(), r.end());
+        }
+        for (int j = 1; j <= L + 1; ++j) {
+          const std::vector<float> r = bn_row(j, true);
+          prm.insert(prm.end(), r.begin(), r.end());
         }
       }
       p3hip_engine::BlockwRun run;
@@ -600,7 +620,7 @@ bool build_plan(p3hip_engine* e, Arena& ar) {
       run.nblk = (int)n;
       run.stream_off = ar.add(ws.data(), ws.size() * 2);
       run.prm_off = ar.add(prm.data(), prm.size() * 4);
-      if (ws.size() * 2 != n * (size_t)(32 + 72 * L) * 4096 || prm.size() != n * (size_t)(512 + 256 * (L + 1))) ar.bad_stream = true;
+      if (ws.size() * 2 != n * (size_t)(32 + 72 * L) * 4096 || prm.size() != n * (size_t)(512 + 128 * (L + 1))) ar.bad_stream = true;
       e->bw_runs.push_back(run);
       bi += n;
     }

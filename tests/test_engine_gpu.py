@@ -364,6 +364,59 @@ def test_broadcast_convs_inside_block_launches_match_their_own_launches(built, t
         assert np.array_equal(a, res["not_joined"][name]), name
 
 
+_BLOCKW_CHILD = r"""
+import sys, os
+sys.path.insert(0, %r)
+import numpy as np
+from conftest import load_golden
+from p3achygo_amd import engine, features, netspec
+out = {}
+for name in ("test_b3c256btl1", "test_b5c256btl2_i2", "test_b10c256btl1_i2", "b12c256btl3"):
+    cfg = netspec.CONFIGS[name]
+    gold, pos = load_golden(name)
+    W = netspec.generate_weights(cfg, randomize=True)
+    path = os.path.join(sys.argv[1], name + ".p3w")
+    netspec.save_p3w(path, cfg, W)
+    pad = features.random_positions(300 - len(pos), seed=9, n_games=11)
+    allpos = np.concatenate([pos, pad])
+    eng = engine.HipEngine(path, len(allpos))
+    eng.load_all(allpos); eng.RunInference()
+    out[name] = np.stack([eng.get_raw(i) for i in range(len(allpos))])
+    eng.close()
+np.savez(sys.argv[2], **out)
+"""
+
+
+@pytest.mark.gpu
+def test_hand_scheduled_block_kernel_matches_the_fixtures_and_the_hip_kernels(built, tmp_path):
+    """k_blockw (csrc/asm/blockw_gen.py, opt-in: P3HIP_BLOCKW=1): the runs of C = 256 btl blocks by the generated
+    one-wave-per-SIMD assembly kernel, the broadcast blocks as their own launches.  Its BN scales ride in the fp16 weights
+    (one rounding of w * scale instead of rounding w and multiplying in fp32), so it differs from the HIP kernels by fp16
+    roundings of the intermediates — both stay inside the logit bound against the float64 fixtures, and inside it of each
+    other over 300 positions (4 positions per workgroup slot at 256 CUs is not reached; more than one, with 300)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for label, extra in (("hip", {"P3HIP_NO_BFUSE": "1"}), ("blockw", {"P3HIP_BLOCKW": "1"})):
+        env = dict(os.environ)
+        for k in ("P3HIP_NO_BFUSE", "P3HIP_BLOCKW", "P3HIP_BLOCKW_DIAG"):
+            env.pop(k, None)
+        env.update(extra)
+        env["PYTHONPATH"] = os.path.join(root, "tests") + os.pathsep + env.get("PYTHONPATH", "")
+        path = str(tmp_path / (label + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _BLOCKW_CHILD % root, str(tmp_path), path], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[label] = np.load(path)
+    for name in res["hip"].files:
+        a, b = res["blockw"][name], res["hip"][name]
+        assert not np.isnan(a).any()
+        assert _logits_close(a[:, :1889], b[:, :1889]), name
+        gold, gpos = load_golden(name)
+        n = len(gpos)
+        assert _logits_close(a[:n, :1887], np.asarray(gold["raw"], np.float64)[:, :1887]), name
+
+
 @pytest.mark.gpu
 def test_thread_per_game_nn_interface_on_hip_engine(built, weight_files):
     """The reference's blocking NNInterface (host/nn_interface.h) over the HIP engine: 32 game

@@ -20,7 +20,10 @@ from p3achygo_amd import engine, features, netspec
 mode, name, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 cfg = netspec.CONFIGS[name]
 path = os.path.join(tempfile.mkdtemp(), "n.p3w")
-netspec.save_p3w(path, cfg, netspec.generate_weights(cfg, randomize=True))
+Wts = netspec.generate_weights(cfg, randomize=True)
+if os.environ.get("P3_AB_ZERO"):      # every MFMA operand zero: the chip holds its full clock (DESIGN.md section 4, the clock)
+    Wts = {k: (np.zeros_like(v) if not k.endswith(".var") else v) for k, v in Wts.items()}
+netspec.save_p3w(path, cfg, Wts)
 pos = features.random_positions(batch, seed=5, n_games=9)
 eng = engine.HipEngine(path, batch)
 eng.load_all(pos)
@@ -59,7 +62,7 @@ eng.close()
 
 def run(mode, name, batch, env_extra, out, timeout=180):
     env = dict(os.environ)
-    for k in ("P3HIP_BLOCKW", "P3HIP_BLOCKW_DIAG", "P3HIP_NO_BFUSE"):
+    for k in ("P3HIP_BLOCKW", "P3HIP_BLOCKW_DIAG", "P3HIP_NO_BFUSE", "P3_AB_ZERO"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", CHILD % ROOT, mode, name, str(batch), out], env=env, capture_output=True,
@@ -120,13 +123,14 @@ def main():
         print("sample ref  [pos 0, ch 128..131, loc 180..187]\n", x[0, 128:132, 180:188])
         print("sample new  [pos 0, ch 128..131, loc 180..187]\n", y[0, 128:132, 180:188])
         sys.exit(0)
-    if what == "time":
+    if what in ("time", "timezero"):
         name = sys.argv[2] if len(sys.argv) > 2 else "b12c256btl3"
         batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+        zero = {"P3_AB_ZERO": "1"} if what == "timezero" else {}
         for rnd in range(2):
             for label, env in (("joined", {}), ("blocks_only", {"P3HIP_NO_BFUSE": "1"}), ("blockw", {"P3HIP_BLOCKW": "1"})):
-                out = run("time", name, batch, env, "-")
-                print(label, (out or "").strip().splitlines()[-1] if out else "FAILED", flush=True)
+                out = run("time", name, batch, dict(env, **zero), "-")
+                print(("zero-data " if zero else "") + label, (out or "").strip().splitlines()[-1] if out else "FAILED", flush=True)
     if what == "stamps":
         name = sys.argv[2] if len(sys.argv) > 2 else "b12c256btl3"
         batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
@@ -134,9 +138,9 @@ def main():
         if run("stamps", name, batch, {"P3HIP_BLOCKW": "1", "P3HIP_BLOCKW_DIAG": "1"}, out) is None:
             sys.exit(1)
         st = np.load(out).astype(np.int64)      # [wg 8][block 16][wave 4][24]
-        print("HW_REG_LDS_ALLOC of workgroup 0, block 0, waves 0..3: " + " ".join(hex(int(v)) for v in st[0, 0, :, 23]))
+
         blk = st[:, 1]                           # the run's second block: steady state
-        n = int((blk[0, 0] != 0).sum())
+        n = int((blk[0, 0, :21] != 0).sum())
         d = np.diff(blk[:, :, :n], axis=2)       # [wg][wave][section]
         print("sections (cycles, median over 8 workgroups x 4 waves), block 1 of run 0:")
         print(np.median(d.reshape(-1, n - 1), axis=0).astype(int).tolist())
@@ -144,6 +148,9 @@ def main():
         for w in range(4):
             print(w, d[0, w].tolist())
         print("block total:", int(np.median(blk[:, :, n - 1] - blk[:, :, 0])))
+        rt = (blk[:, :, 22] - blk[:, :, 21]).astype(np.float64) * 10e-9
+        cyc = (blk[:, :, 23] - blk[:, :, 0]).astype(np.float64)
+        print("in-kernel clock over the block: %.3f GHz; block wall %.1f us" % (float(np.median(cyc / rt)) / 1e9, float(np.median(rt)) * 1e6))
 
 
 if __name__ == "__main__":

@@ -10,6 +10,7 @@
 //   * only the consumed outputs (7,556 B / position) come back every run; ownership and
 //     raw logits stay on the device until asked for.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <atomic>
 #include <cmath>
@@ -244,6 +245,7 @@ struct p3hip_engine {
   hipGraphExec_t graph_exec = nullptr;
   bool graph_failed = false, graph_warm = false;
   const unsigned char* graph_feats = nullptr;   // the feature buffer the captured k_init reads (kernel arguments are baked in)
+  bool graph_direct = false;                    // ... and whether the captured heads kernel writes the host result buffer
   // p3hip_time_trunk_kernel: event pairs around every fused-block launch of a forward pass
   std::vector<hipEvent_t> blk_ev;
   bool time_blocks = false;
@@ -272,6 +274,12 @@ struct p3hip_engine {
   float* d_hp = nullptr;
   float* d_out = nullptr;
   float* h_out = nullptr;  // pinned [batch][kResultFloats]
+  float* d_res = nullptr;  // [batch][kResultFloats] dense: the heads kernel writes the result records a second time there
+                           // (run_direct), so that the D2H copy is ONE contiguous transfer instead of a strided one
+  bool run_direct = false; // this run's heads kernel fills d_res
+  double t_h2d = 0, t_fwd = 0, t_d2h = 0;   // P3HIP_TIME_RUN
+  long t_runs = 0;
+  bool feats_identity = false;   // gather_loaded: every slot was dirty, row == slot: the upload comes straight from h_feats
   p3::SlotStates slots;   // dirty flags + slot -> dense row of the last run (slot_state.h)
   int last_n = 0;
   std::vector<unsigned char> slot_sym, row_sym;   // symmetry given with a keyed load, by slot / by row of the last run
@@ -1007,6 +1015,7 @@ bool enqueue_forward(p3hip_engine* e, int npos) {
     h.conv_a = e->d_arena + e->heads_conv_a_off;
     h.image = e->dev<float>(e->heads_image_off);
     h.hp = e->d_hp; h.out = e->d_out; h.npos = npos; h.V = wf.V;
+    h.res = e->run_direct ? e->d_res : nullptr;
     auto F = [&](const char* n) { return e->dev<float>(e->head_off.at(n)); };
     h.gbn_scale = F("gbn_scale"); h.gbn_shift = F("gbn_shift");
     h.gd_w = F("policy.gpool_dense.w"); h.gd_b = F("policy.gpool_dense.b");
@@ -1040,7 +1049,7 @@ bool run_forward(p3hip_engine* e, int npos) {
   // e->d_feats at the cache's gathered copy around its forward pass: a graph captured for one buffer must never be
   // replayed for the other.  The graph serves the buffer it was captured on; the other goes out kernel by kernel.
   if (e->graph_exec) {
-    if (e->d_feats != e->graph_feats) return enqueue_forward(e, npos);
+    if (e->d_feats != e->graph_feats || e->run_direct != e->graph_direct) return enqueue_forward(e, npos);
     return e->check(hipGraphLaunch(e->graph_exec, e->stream), "hipGraphLaunch");
   }
   if (!e->graph_warm) {
@@ -1064,6 +1073,7 @@ bool run_forward(p3hip_engine* e, int npos) {
   }
   e->graph = g;
   e->graph_feats = e->d_feats;
+  e->graph_direct = e->run_direct;
   return e->check(hipGraphLaunch(e->graph_exec, e->stream), "hipGraphLaunch");
 }
 
@@ -1116,6 +1126,7 @@ p3hip_engine* p3hip_create(const char* weights_path, int batch_size, int version
             e->check(hipHostMalloc((void**)&e->h_feats, B * kFeatBytes, hipHostMallocDefault), "hipHostMalloc") &&
             e->check(hipHostMalloc((void**)&e->h_feats_compact, B * kFeatBytes, hipHostMallocDefault), "hipHostMalloc") &&
             e->check(hipHostMalloc((void**)&e->h_out, B * p3::kResultFloats * 4, hipHostMallocDefault), "hipHostMalloc") &&
+            e->check(hipMalloc((void**)&e->d_res, B * p3::kResultFloats * 4), "hipMalloc results") &&
             e->check(hipMalloc((void**)&e->d_feats, B * kFeatBytes), "hipMalloc feats") &&
             e->check(hipMalloc((void**)&e->d_x, B * C * kNLoc * 2), "hipMalloc x") &&
             e->check(hipMalloc((void**)&e->d_t, B * C * kNLoc * 2), "hipMalloc t") &&
@@ -1139,7 +1150,7 @@ void p3hip_destroy(p3hip_engine* e) {
   if (e->stream || e->d_arena) (void)hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   hipFree(e->d_arena); hipFree(e->d_feats); hipFree(e->d_x); hipFree(e->d_t); hipFree(e->d_u); hipFree(e->d_s);
-  hipFree(e->d_hp); hipFree(e->d_out);
+  hipFree(e->d_hp); hipFree(e->d_out); hipFree(e->d_res);
   hipFree(e->d_bw_stamps);
   if (e->bw_mod) hipModuleUnload(e->bw_mod);
   {
@@ -1245,8 +1256,13 @@ int p3hip_cache_stats(const p3hip_engine* e, uint64_t out[4]) {
 // Compacts every dirty slot (loaded and not yet fetched, slot_state.h) into the dense upload.
 static int gather_loaded(p3hip_engine* e) {
   const bool all = (e->flags & P3HIP_FLAG_RUN_ALL_SLOTS) != 0;
+  // When every slot of the static batch is evaluated (the common case: NNInterface fills the whole batch, the self-play
+  // scheduler always does) the dense upload IS h_feats: no second host copy of 1.9 MB per run.
+  std::vector<std::pair<int, int>> moved;
+  bool identity = true;
   const int n = e->slots.gather(all, [&](int s, int row) {
-    memcpy(e->h_feats_compact + (size_t)row * kFeatBytes, e->h_feats + (size_t)s * kFeatBytes, kFeatBytes);
+    if (s != row) identity = false;
+    moved.emplace_back(s, row);
     e->row_sym[row] = e->slot_sym[s];
     if (e->cache.on) {
       e->cache.h_keys[row] = e->cache.h_slot_keys[s];
@@ -1255,6 +1271,10 @@ static int gather_loaded(p3hip_engine* e) {
       e->cache.h_sym[row] = (unsigned)e->cache.h_slot_keys[s].sym;
     }
   });
+  e->feats_identity = identity && n == e->batch && !e->cache.on;
+  if (!e->feats_identity)
+    for (const auto& m : moved)
+      memcpy(e->h_feats_compact + (size_t)m.second * kFeatBytes, e->h_feats + (size_t)m.first * kFeatBytes, kFeatBytes);
   e->last_n = n;
   return n;
 }
@@ -1263,7 +1283,7 @@ int p3hip_upload(p3hip_engine* e) {
   if (!e->bind()) return 1;
   int n = gather_loaded(e);
   if (n == 0) return 0;
-  if (!e->check(hipMemcpyAsync(e->d_feats, e->h_feats_compact, (size_t)n * kFeatBytes,
+  if (!e->check(hipMemcpyAsync(e->d_feats, e->feats_identity ? e->h_feats : e->h_feats_compact, (size_t)n * kFeatBytes,
                                hipMemcpyHostToDevice, e->stream), "H2D features")) return 1;
   return e->check(hipStreamSynchronize(e->stream), "sync") ? 0 : 1;
 }
@@ -1353,12 +1373,48 @@ int p3hip_run(p3hip_engine* e) {
   int n = gather_loaded(e);
   if (n == 0) return 0;
   if (e->cache.on) return run_cached(e, n);
-  if (!e->check(hipMemcpyAsync(e->d_feats, e->h_feats_compact, (size_t)n * kFeatBytes,
+  if (!e->check(hipMemcpyAsync(e->d_feats, e->feats_identity ? e->h_feats : e->h_feats_compact, (size_t)n * kFeatBytes,
                                hipMemcpyHostToDevice, e->stream), "H2D features")) return 1;
-  if (!run_forward(e, n)) return 1;
-  if (!e->check(hipMemcpy2DAsync(e->h_out, p3::kResultFloats * 4, e->d_out, p3::kOutStride * 4,
-                                 p3::kResultFloats * 4, n, hipMemcpyDeviceToHost, e->stream), "D2H results")) return 1;
-  return e->check(hipStreamSynchronize(e->stream), "sync") ? 0 : 1;
+  // The heads kernel writes the result records (the first kResultFloats of an output row) a second time into a dense
+  // device buffer (HeadsArgs::res), so the copy TrtEngineImpl::RunInference queues behind its graph (trt_engine.cc:283-297)
+  // is one contiguous 7.7 MB transfer at the link's rate; the strided copy of rounds 1-3 (1024 rows of 7,556 B out of a
+  // 13,664 B pitch) took 0.45 ms, and 4-byte stores straight into host memory from the kernel took as long (round 4,
+  // gpurun_out/r4d/breakdown.log).  P3HIP_NO_DIRECT_RESULTS=1: the strided copy (A/B, tests).
+  static const bool no_direct = getenv("P3HIP_NO_DIRECT_RESULTS") != nullptr;
+  // P3HIP_TIME_RUN=1 (tools/gpu_run_breakdown.py): the stream is drained after every stage and the stages' wall times are
+  // summed into the engine's error string on request — a measurement aid, never set in production
+  static const bool time_run = getenv("P3HIP_TIME_RUN") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t_start = now();
+  if (time_run) {
+    hipStreamSynchronize(e->stream);
+    e->t_h2d += std::chrono::duration<double>(now() - t_start).count();
+    t_start = now();
+  }
+  e->run_direct = e->d_res != nullptr && !no_direct;
+  const bool ok = run_forward(e, n);
+  if (time_run) {
+    hipStreamSynchronize(e->stream);
+    e->t_fwd += std::chrono::duration<double>(now() - t_start).count();
+    t_start = now();
+  }
+  const bool direct = e->run_direct;
+  e->run_direct = false;
+  if (!ok) return 1;
+  if (direct) {
+    if (!e->check(hipMemcpyAsync(e->h_out, e->d_res, (size_t)n * p3::kResultFloats * 4, hipMemcpyDeviceToHost, e->stream), "D2H results")) return 1;
+  } else if (!e->check(hipMemcpy2DAsync(e->h_out, p3::kResultFloats * 4, e->d_out, p3::kOutStride * 4,
+                                        p3::kResultFloats * 4, n, hipMemcpyDeviceToHost, e->stream), "D2H results")) return 1;
+  const bool sync_ok = e->check(hipStreamSynchronize(e->stream), "sync");
+  if (time_run) {
+    e->t_d2h += std::chrono::duration<double>(now() - t_start).count();
+    ++e->t_runs;
+    char buf[200];
+    snprintf(buf, sizeof buf, "timing: runs %ld  h2d %.1f us  forward %.1f us  d2h %.1f us", e->t_runs, e->t_h2d / e->t_runs * 1e6,
+             e->t_fwd / e->t_runs * 1e6, e->t_d2h / e->t_runs * 1e6);
+    e->err = buf;
+  }
+  return sync_ok ? 0 : 1;
 }
 
 int p3hip_get_slot(p3hip_engine* e, int slot, p3hip_result* out) {

@@ -151,6 +151,9 @@ struct HeadsArgs {
   const void* conv_a;       // [6 cout tiles][C/32 k32 steps][64 lanes][8] fp16
   const float* image;       // heads_image_floats(32, V) floats, 16-byte aligned
   float* out;       // [npos][kOutStride]
+  // p3hip_run's result records (the first kResultFloats of a row) written a second time into a dense buffer, so that the
+  // D2H copy of TrtEngineImpl::RunInference (trt_engine.cc:283-297) is one contiguous transfer; null: d_out only
+  float* res;       // [npos][kResultFloats]
   int npos;
   int V;
   const float *gbn_scale, *gbn_shift;      // policy.gpool_bn folded [32]

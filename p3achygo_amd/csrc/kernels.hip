@@ -976,6 +976,7 @@ __global__ void __launch_bounds__(1024) k_heads(HeadsArgs a) {
     // (k_conv1x1's EPI 2); quads 0 .. H/4-1 = p, H/4 .. 2H/4-1 = g, 2H/4 .. 3H/4-1 = v
     const f32x4* __restrict__ hp4 = (const f32x4*)(a.hp + (size_t)pos * 3 * H * kNLoc);
     float* __restrict__ out = a.out + (size_t)pos * kOutStride;
+    float* __restrict__ res = a.res ? a.res + (size_t)pos * kResultFloats : nullptr;
     // ---- pooled g (after bn+mish) and pooled v (raw): one wave per channel quad, six 16-byte loads in
     // flight -------------------------------------------------------------------------------------------
     static_assert(H % 4 == 0, "channel quads");
@@ -1050,7 +1051,10 @@ __global__ void __launch_bounds__(1024) k_heads(HeadsArgs a) {
       if (t < 2) sc[L::misc + t] = s;
       if (live) {
         if (t < 2) out[kOffOutcomeLogits + t] = s;
-        if (t == 5) out[kOffErr2] = 4.0f / (1.0f + __expf(-s));
+        if (t == 5) {
+          out[kOffErr2] = 4.0f / (1.0f + __expf(-s));
+          if (res) res[kOffErr2] = out[kOffErr2];
+        }
       }
     } else if (t == 64) {
       float s = gamma_out_b;
@@ -1111,6 +1115,7 @@ __global__ void __launch_bounds__(1024) k_heads(HeadsArgs a) {
       if (live) {
         out[kOffMoveLogits + i] = p;
         out[kOffOptLogits + i] = o;
+        if (res) res[kOffMoveLogits + i] = p;
       }
       m3[0] = fmaxf(m3[0], p);
       m3[1] = fmaxf(m3[1], o);
@@ -1159,14 +1164,25 @@ __global__ void __launch_bounds__(1024) k_heads(HeadsArgs a) {
       for (int i = t; i < 362; i += 256) {
         out[kOffMoveProbs + i] = sc[L::pi + i] * i0;
         out[kOffOptProbs + i] = sc[L::opt + i] * i1;
+        if (res) {
+          res[kOffMoveProbs + i] = sc[L::pi + i] * i0;
+          res[kOffOptProbs + i] = sc[L::opt + i] * i1;
+        }
       }
-      for (int i = t; i < 800; i += 256) out[kOffScoreProbs + i] = sc[L::logits + i] * i2;
+      for (int i = t; i < 800; i += 256) {
+        out[kOffScoreProbs + i] = sc[L::logits + i] * i2;
+        if (res) res[kOffScoreProbs + i] = sc[L::logits + i] * i2;
+      }
       if (t == 0) {
         const float v0 = sc[L::misc], v1 = sc[L::misc + 1];
         const float m = fmaxf(v0, v1);
         const float e0 = __expf(v0 - m), e1 = __expf(v1 - m);
         out[kOffValueProbs] = e0 / (e0 + e1);
         out[kOffValueProbs + 1] = e1 / (e0 + e1);
+        if (res) {
+          res[kOffValueProbs] = e0 / (e0 + e1);
+          res[kOffValueProbs + 1] = e1 / (e0 + e1);
+        }
       }
     }
     __syncthreads();
@@ -1234,6 +1250,7 @@ __global__ void __launch_bounds__(512, 2) k_headsx(HeadsArgs a) {
     const bool live = pos2 + g < a.npos;
     const int pos = live ? pos2 + g : a.npos - 1;   // an idle group recomputes the last position
     float* __restrict__ out = a.out + (size_t)pos * kOutStride;
+    float* __restrict__ res = a.res ? a.res + (size_t)pos * kResultFloats : nullptr;
     const _Float16* __restrict__ xp = a.x + (size_t)pos * C * kNLoc;
     // per-lane constants of this lane's 8 channels (cout tiles 2u and 2u + 1 of a head: channels 16u' + 4q + i)
     float bsc[2][4], bsh[2][4], ownw[2][4];
@@ -1366,7 +1383,10 @@ __global__ void __launch_bounds__(512, 2) k_headsx(HeadsArgs a) {
       if (t < 2) sc[L::misc + t] = s_;
       if (live) {
         if (t < 2) out[kOffOutcomeLogits + t] = s_;
-        if (t == 5) out[kOffErr2] = 4.0f / (1.0f + __expf(-s_));
+        if (t == 5) {
+          out[kOffErr2] = 4.0f / (1.0f + __expf(-s_));
+          if (res) res[kOffErr2] = out[kOffErr2];
+        }
       }
     } else if (t == 64) {
       float s_ = gamma_out_b;
@@ -1440,6 +1460,7 @@ __global__ void __launch_bounds__(512, 2) k_headsx(HeadsArgs a) {
       if (live) {
         out[kOffMoveLogits + i] = p;
         out[kOffOptLogits + i] = o;
+        if (res) res[kOffMoveLogits + i] = p;
       }
       m3[0] = fmaxf(m3[0], p);
       m3[1] = fmaxf(m3[1], o);
@@ -1488,14 +1509,25 @@ __global__ void __launch_bounds__(512, 2) k_headsx(HeadsArgs a) {
       for (int i = t; i < 362; i += 256) {
         out[kOffMoveProbs + i] = sc[L::pi + i] * i0;
         out[kOffOptProbs + i] = sc[L::opt + i] * i1;
+        if (res) {
+          res[kOffMoveProbs + i] = sc[L::pi + i] * i0;
+          res[kOffOptProbs + i] = sc[L::opt + i] * i1;
+        }
       }
-      for (int i = t; i < 800; i += 256) out[kOffScoreProbs + i] = sc[L::logits + i] * i2;
+      for (int i = t; i < 800; i += 256) {
+        out[kOffScoreProbs + i] = sc[L::logits + i] * i2;
+        if (res) res[kOffScoreProbs + i] = sc[L::logits + i] * i2;
+      }
       if (t == 0) {
         const float v0 = sc[L::misc], v1 = sc[L::misc + 1];
         const float m = fmaxf(v0, v1);
         const float e0 = __expf(v0 - m), e1 = __expf(v1 - m);
         out[kOffValueProbs] = e0 / (e0 + e1);
         out[kOffValueProbs + 1] = e1 / (e0 + e1);
+        if (res) {
+          res[kOffValueProbs] = e0 / (e0 + e1);
+          res[kOffValueProbs + 1] = e1 / (e0 + e1);
+        }
       }
     }
     __syncthreads();

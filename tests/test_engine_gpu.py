@@ -364,6 +364,52 @@ def test_broadcast_convs_inside_block_launches_match_their_own_launches(built, t
         assert np.array_equal(a, res["not_joined"][name]), name
 
 
+_DIRECT_CHILD = r"""
+import sys, os, tempfile
+sys.path.insert(0, %r)
+import numpy as np
+from p3achygo_amd import engine, features, netspec
+cfg = netspec.CONFIGS["test_b3c256btl1"]
+path = os.path.join(tempfile.mkdtemp(), "n.p3w")
+netspec.save_p3w(path, cfg, netspec.generate_weights(cfg, randomize=True))
+pos = features.random_positions(70, seed=41, n_games=10)
+out = []
+for flags in (0, engine.FLAG_LAUNCH_GRAPH):
+    eng = engine.HipEngine(path, 64, flags=flags)
+    for rnd in range(4):
+        idx = list(range(64)) if rnd != 2 else [5, 9, 33]          # full batches (rows = slots) and a ragged, compacted one
+        for i in idx:
+            eng.LoadBatch(i, pos[(i + rnd) %% 70:(i + rnd) %% 70 + 1])
+        eng.RunInference()
+        for i in idx:
+            r = eng.GetBatch(i)
+            out.append(np.concatenate([np.ctypeslib.as_array(getattr(r, k)).ravel() for k in
+                                       ("move_logits", "move_probs", "value_probs", "score_probs", "opt_move_probs")] + [[r.err2_outcome]]))
+    eng.close()
+np.save(sys.argv[1], np.stack(out))
+"""
+
+
+@pytest.mark.gpu
+def test_result_records_written_by_the_heads_kernel_equal_the_copied_ones(built, tmp_path):
+    """p3hip_run's result records reach the pinned host buffer from inside the heads kernel (HeadsArgs::res; the D2H copy of
+    trt_engine.cc:283-297 folded into the kernel that produces the values).  Bit for bit what the strided copy behind the
+    forward pass delivers (P3HIP_NO_DIRECT_RESULTS=1), for full batches, a compacted ragged run, and under the launch graph."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for extra in ({}, {"P3HIP_NO_DIRECT_RESULTS": "1"}):
+        env = dict(os.environ)
+        env.pop("P3HIP_NO_DIRECT_RESULTS", None)
+        env.update(extra)
+        path = str(tmp_path / ("d%d.npy" % len(res)))
+        r = subprocess.run([sys.executable, "-c", _DIRECT_CHILD % root, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(path))
+    assert res[0].shape == res[1].shape and res[0].shape[0] == 2 * (3 * 64 + 3)
+    assert not np.isnan(res[0]).any() and np.array_equal(res[0], res[1])
+
+
 _BLOCKW_CHILD = r"""
 import sys, os
 sys.path.insert(0, %r)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile on the GPU box (run through gpurun from the repo root):
-#   1. rocprofv3 --kernel-trace --stats around the default bench.py command (shorter --steps: four
+#   1. rocprofv3 --kernel-trace --stats around the default bench.py command (128 rounds: eight
 #      game groups' streams share the GPU, kernel wall durations include time-slicing), and around
 #      20 single-stream forward passes (what bench.py's roofline leg times with HIP events)
 #   2. FETCH_SIZE and WRITE_SIZE of three resident forward passes, separate passes (HBM traffic)
@@ -12,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/${TAG}_prof_bench -o b -- python3 $R/bench.py --steps 1024 --no-cpu-baseline --no-pmc > $OUT/${TAG}_bench_under_rocprof.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/${TAG}_prof_bench -o b -- python3 $R/bench.py --steps 128 --no-cpu-baseline --no-pmc > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/${TAG}_prof_engine -o e -- python3 $R/tools/gpu_run_forward.py 20 > $OUT/${TAG}_engine_under_rocprof.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_f -o p -- python3 $R/tools/gpu_run_forward.py 3 > $OUT/${TAG}_pmc_f.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_w -o p -- python3 $R/tools/gpu_run_forward.py 3 > $OUT/${TAG}_pmc_w.log 2>&1

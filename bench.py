@@ -118,7 +118,7 @@ def hbm_traffic(kernel_name, positions):
     needs the profiler around the whole process, so the number is a RECORDED measurement of this
     kernel at this batch size, not re-measured inside the timed run; null when no profile of this
     build's kernel matches."""
-    for name in ("r03_k_block_hbm_traffic.json", "r02_k_block_hbm_traffic.json"):
+    for name in ("r04_k_block_hbm_traffic.json", "r03_k_block_hbm_traffic.json", "r02_k_block_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 prof = json.load(f)

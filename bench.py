@@ -419,22 +419,37 @@ def main():
                         "loop_positions_per_s also counts the loads and gets"}
         except Exception as ex:   # noqa: BLE001
             extras["engine_benchmark"] = {"error": repr(ex)}
-        # BASELINE configs[2] exactly as written: 1024 concurrent games, batch 1024 = ONE game group, so the
-        # GPU idles while the host advances the games and the host idles during the forward pass
+        # BASELINE configs[2] exactly as written: 1024 concurrent games, batch 1024 = ONE game group.  With one lane the
+        # GPU idles while the host advances the games and the host idles during the forward pass (`one_lane`); with two
+        # lanes (two engine instances filled in turn by the same 1024 games, up to 4 playouts of a search waiting for
+        # results at once — the games and every result are the same, tests/test_selfplay_cpu.py) the group overlaps
+        # its host work with its own forward passes (`value`)
         try:
             host_api.set_groups(1)
             host_api.set_step_limit(512)
             host_api.set_advance_limit(args.advance_limit)
+            host_api.set_lanes(2, 4)
+            s2 = host_api.selfplay_run(path, args.batch, threads, 0.0, default_n=32, default_k=5, selected_n=32,
+                                       selected_k=5, warmup_batches=8, seed=177, device=local_rank)
+            host_api.set_lanes(1, 1)
             s1 = host_api.selfplay_run(path, args.batch, threads, 0.0, default_n=32, default_k=5, selected_n=32,
                                        selected_k=5, warmup_batches=8, seed=177, device=local_rank)
             extras["as_stated_c3"] = {
-                "value": s1.positions / s1.seconds, "unit": "positions/s", "steps": s1.batches,
-                "concurrent_games": args.batch, "game_groups": 1, "evals_per_move": s1.positions / max(s1.moves, 1),
-                "gpu_share_of_time": s1.gpu_seconds / s1.seconds, "host_share_of_time": s1.host_seconds / s1.seconds,
-                "what": "BASELINE configs[2] as stated (1024 concurrent games, inference batch 1024): one game group, "
-                        "host and GPU alternate; the headline keeps `game_groups_per_gpu` groups in flight instead"}
+                "value": s2.positions / s2.seconds, "unit": "positions/s", "steps": s2.batches,
+                "concurrent_games": args.batch, "game_groups": 1, "lanes": 2, "playouts_in_flight_per_game": 4,
+                "mean_batch_fill": s2.positions / max(s2.batches, 1) / args.batch,
+                "evals_per_move": s2.positions / max(s2.moves, 1),
+                "host_share_of_time": s2.host_seconds / s2.seconds,
+                "one_lane": {"value": s1.positions / s1.seconds, "steps": s1.batches,
+                             "gpu_share_of_time": s1.gpu_seconds / s1.seconds,
+                             "host_share_of_time": s1.host_seconds / s1.seconds},
+                "what": "BASELINE configs[2] as stated (1024 concurrent games, inference batch 1024): ONE game group whose "
+                        "games fill two engine batches in turn, so its host work overlaps its own forward passes; "
+                        "`one_lane` = the same group with host and GPU alternating (rounds 1-3); the headline keeps "
+                        "`game_groups_per_gpu` one-lane groups in flight instead"}
         except Exception as ex:   # noqa: BLE001
             extras["as_stated_c3"] = {"error": repr(ex)}
+            host_api.set_lanes(1, 1)
         finally:
             host_api.set_groups(GROUPS)
             host_api.set_step_limit(0)

@@ -6,8 +6,11 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/p3hip.h"
 #include "board.h"
@@ -48,6 +51,46 @@ struct NullEvaluator final : Evaluator {
     r.score_probs[400] = 1.0f;
     r.err2_outcome = 0.0f;
   }
+};
+
+// A deterministic stand-in for a trained network (test aid): every output is a hash of the feature record, so
+// different positions get different policies, outcomes and scores, the same position always the same ones,
+// whatever batch or slot it is evaluated in.  Lets tests compare whole searches and games across schedules.
+struct HashEvaluator final : Evaluator {
+  std::vector<p3hip_features> slots;
+  std::vector<p3hip_result> results;   // of the last run: a slot may be reloaded before its old result is fetched
+  std::vector<char> dirty;
+  explicit HashEvaluator(int n) : slots((size_t)n), results((size_t)n), dirty((size_t)n, 0) {}
+  void Load(int slot, const p3hip_features& f) override { slots[(size_t)slot] = f; dirty[(size_t)slot] = 1; }
+  bool Run() override {
+    for (size_t i = 0; i < slots.size(); ++i)
+      if (dirty[i]) { Evaluate(slots[i], results[i]); dirty[i] = 0; }
+    return true;
+  }
+  static uint64_t Mix(uint64_t x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+  }
+  static void Evaluate(const p3hip_features& f, p3hip_result& r) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(&f);
+    for (size_t i = 0; i < sizeof f; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+    auto unit = [h](uint64_t i) { return float(Mix(h + i * 0x9e3779b97f4a7c15ull) >> 40) * (1.0f / 16777216.0f); };
+    float mx = -1e30f, sum = 0;
+    for (int i = 0; i < kNumMoves; ++i) { r.move_logits[i] = 6.0f * unit(i) - 3.0f; mx = std::max(mx, r.move_logits[i]); }
+    for (int i = 0; i < kNumMoves; ++i) { r.move_probs[i] = std::exp(r.move_logits[i] - mx); sum += r.move_probs[i]; }
+    for (int i = 0; i < kNumMoves; ++i) { r.move_probs[i] /= sum; r.opt_move_probs[i] = r.move_probs[i]; }
+    const float win = 0.05f + 0.9f * unit(1000);
+    r.value_probs[0] = 1.0f - win;
+    r.value_probs[1] = win;
+    for (int i = 0; i < P3HIP_NUM_SCORE_LOGITS; ++i) r.score_probs[i] = 0.0f;
+    const int centre = 400 + int(40.0f * unit(1001)) - 20;
+    r.score_probs[centre] = 0.6f;
+    r.score_probs[centre + 3] = 0.4f;
+    r.err2_outcome = 0.1f * unit(1002);
+  }
+  void Get(int slot, p3hip_result& r) override { r = results[(size_t)slot]; }
 };
 
 // The HIP engine, bound through its C ABI exactly as a foreign host would bind it.

@@ -658,6 +658,10 @@ inline int MoveIdx(Loc l) { return l == kPassLoc ? kPassEncoding : Idx(l); }
 class GumbelSearch {
  public:
   enum class Status { kNeedEval, kDone };
+  // IssueNext: an evaluation was requested (eval_game()/eval_color() name it; it stays in flight until Deliver or
+  // ResolveBack), nothing can start before a result in flight arrives, or the search is complete
+  enum class Issue { kNeedEval, kBlocked, kDone };
+  static constexpr int kMaxInflight = 4;
 
   // `game`, `pool`, `prob` must outlive the search.  `root` must belong to `pool`.
   void Begin(Game* game, NodePool* pool, TreeNode* root, Color color, const GumbelParams& p,
@@ -667,6 +671,8 @@ class GumbelSearch {
     root_pos_ = Position(*game);
     state_ = root->evaluated ? State::kPrepare : State::kRootEval;
     res_ = GumbelResult();
+    head_ = count_ = 0;
+    have_pending_ = false;
   }
 
   // SearchRootPuct (gumbel.cc:563-666) with PuctRootSelectionPolicy::kVisitCountSample as
@@ -683,49 +689,79 @@ class GumbelSearch {
   }
 
   // Runs until an evaluation is needed (then eval_game()/eval_color() name the position) or
-  // the search is complete (result()).
+  // the search is complete (result()): one evaluation in flight, the reference's order of work.
   Status Step() {
+    if (have_pending_) { have_pending_ = false; Deliver(pending_); }
+    return IssueNext(1) == Issue::kNeedEval ? Status::kNeedEval : Status::kDone;
+  }
+  void Resume(const p3hip_result& r) { pending_ = r; have_pending_ = true; }
+
+  // Several evaluations in flight (round 4).  Within one sequential-halving round the playouts of different
+  // considered actions touch disjoint subtrees — a playout starts at its action's child of the root
+  // (gumbel.cc:412-452) and only that child's subtree is read by its descent and written by its backup — and the
+  // root's own statistics are read only when a round closes or an early-stopping check runs.  So a playout may
+  // start while others wait for their evaluations if its action differs from all of theirs and no such read lies
+  // between: the tree, the order of evaluation requests and every result are the ones the one-at-a-time search
+  // produces.  Off (one in flight) for a PUCT root, in graph mode and with a bias cache, where playouts share state.
+  // Results come back in request order (Deliver) or, for the request just made, at once (ResolveBack: a cache hit).
+  Issue IssueNext(int max_inflight) {
+    if (puct_root_ || bias_cache_ || pool_->is_graph()) max_inflight = 1;
+    max_inflight = std::min(max_inflight, kMaxInflight);
     for (;;) {
       switch (state_) {
-        case State::kRootEval:
+        case State::kRootEval: {
+          Visit& v = ring_[(head_ + count_) % kMaxInflight];   // nothing else is in flight
+          v.is_root = true;
+          ++count_;
           eval_game_ = &root_pos_;
           eval_color_ = color_;
           state_ = State::kRootEvalWait;
-          return Status::kNeedEval;
-        case State::kRootEvalWait:   // Resume() stored the result
-          EvaluateRoot(pending_, root_, color_);
-          AssignBiasCacheEntry(bias_cache_, root_pos_, root_);   // gumbel.cc:275-278
-          state_ = State::kPrepare;
-          break;
+          return Issue::kNeedEval;
+        }
+        case State::kRootEvalWait:   // Deliver() moves on
+          return Issue::kBlocked;
         case State::kPrepare:
           if (puct_root_) {
             PreparePuct();
           } else if (Prepare()) {
             state_ = State::kDone;
-            return Status::kDone;
+            return Issue::kDone;
           }
           state_ = State::kNextVisit;
           break;
-        case State::kNextVisit:
+        case State::kNextVisit: {
+          if (count_ >= max_inflight) return Issue::kBlocked;
           if (puct_root_) {
-            if (visits_spent_ >= (uint32_t)p_.n) { FinishPuct(); state_ = State::kDone; return Status::kDone; }
-            if (StartVisitPuct()) return Status::kNeedEval;
+            if (visits_spent_ >= (uint32_t)p_.n) { FinishPuct(); state_ = State::kDone; return Issue::kDone; }
+            if (StartVisitPuct()) return Issue::kNeedEval;
             break;
           }
-          if (!AdvanceLoop()) { Finish(); state_ = State::kDone; return Status::kDone; }
-          if (StartVisit()) return Status::kNeedEval;   // else visit completed synchronously
+          const Loop lp = AdvanceLoop(count_ > 0);
+          if (lp == Loop::kWait) return Issue::kBlocked;
+          if (lp == Loop::kStop) { Finish(); state_ = State::kDone; return Issue::kDone; }
+          for (int i = 0; i < count_; ++i)   // same action as a playout in flight: its subtree is not settled
+            if (ring_[(head_ + i) % kMaxInflight].a0 == gm_[cand_].enc) return Issue::kBlocked;
+          if (StartVisit()) return Issue::kNeedEval;   // else the playout completed synchronously
           break;
-        case State::kLeafEvalWait:
-          EvaluateLeaf(pending_, path_.back().node, leaf_color_, color_, root_->init_score_est, score_util_);
-          CompleteVisit();
-          state_ = State::kNextVisit;
-          break;
+        }
         case State::kDone:
-          return Status::kDone;
+          return Issue::kDone;
       }
     }
   }
-  void Resume(const p3hip_result& r) { pending_ = r; }
+  // the result of the OLDEST evaluation in flight
+  void Deliver(const p3hip_result& r) {
+    Visit& v = ring_[head_];
+    head_ = (head_ + 1) % kMaxInflight;
+    --count_;
+    FinishVisit(v, r);
+  }
+  // the result of the evaluation IssueNext just requested (served from a cache): completes at once, like a terminal leaf
+  void ResolveBack(const p3hip_result& r) {
+    --count_;
+    FinishVisit(ring_[(head_ + count_) % kMaxInflight], r);
+  }
+  int inflight() const { return count_; }
   // GumbelEvaluator's bias_cache constructor argument (gumbel.cc:247-254); nullptr = off
   void set_score_utility(const ScoreUtilityParams& sp) { score_util_ = sp; }
   void set_bias_cache(BiasCache* cache) { bias_cache_ = cache; }
@@ -734,9 +770,30 @@ class GumbelSearch {
   const GumbelResult& result() const { return res_; }
 
  private:
-  enum class State { kRootEval, kRootEvalWait, kPrepare, kNextVisit, kLeafEvalWait, kDone };
+  enum class State { kRootEval, kRootEvalWait, kPrepare, kNextVisit, kDone };
+  enum class Loop { kGo, kStop, kWait };
   struct MoveInfo { float prob = 0, logit = 0, noise = 0, qtransform = 0; int enc = -1; };
   struct PathEntry { int action; TreeNode* node; };
+  // one playout: the position it reached, its path, the considered action it started from (-1: a PUCT
+  // playout from the root, or the root's own evaluation)
+  struct Visit {
+    bool is_root = false;
+    int a0 = -1;
+    Position game;
+    std::vector<PathEntry> path;
+    Color leaf_color = kBlack;
+  };
+  void FinishVisit(Visit& v, const p3hip_result& r) {
+    if (v.is_root) {
+      v.is_root = false;
+      EvaluateRoot(r, root_, color_);
+      AssignBiasCacheEntry(bias_cache_, root_pos_, root_);   // gumbel.cc:275-278
+      state_ = State::kPrepare;
+      return;
+    }
+    EvaluateLeaf(r, v.path.back().node, v.leaf_color, color_, root_->init_score_est, score_util_);
+    CompleteVisit(v);
+  }
   static constexpr float kSmallLogit = -10000;
   static constexpr int kVisit = 50;
 
@@ -785,16 +842,18 @@ class GumbelSearch {
     return false;
   }
 
-  // advances (round, visit, candidate) to the next candidate to visit; false when k <= 1.
-  bool AdvanceLoop() {
+  // advances (round, visit, candidate) to the next candidate to visit; kStop when k <= 1.  `busy`: playouts are in
+  // flight, so anything that reads the root children's statistics (closing a round, an early-stopping check) must
+  // wait for them: kWait, with nothing changed.
+  Loop AdvanceLoop(bool busy) {
     for (;;) {
       if (!round_open_) {
-        if (k_ <= 1) return false;
+        if (k_ <= 1) return Loop::kStop;
         visits_per_action_ = (int)std::round(float(p_.n) / float(num_rounds_ * k_));
         visit_num_ = 0;
         cand_ = 0;
         round_open_ = true;
-        if (visits_per_action_ <= 0) { CloseRound(); continue; }
+        if (visits_per_action_ <= 0) { CloseRound(); continue; }   // (a round opens with nothing in flight)
       }
       if (cand_ >= k_) {
         // a sweep over the round's candidates is complete: early-stopping check every
@@ -802,6 +861,7 @@ class GumbelSearch {
         if (p_.early_stopping_enabled) {
           const int interval = (visits_per_action_ + 3) / 4;
           if (interval > 0 && visit_num_ % interval == interval - 1 && visit_num_ >= interval - 1) {
+            if (busy) return Loop::kWait;
             for (int i = 0; i < k_; ++i)
               if (gm_[i].enc >= 0) gm_[i].qtransform = (kVisit + MaxN(root_)) * -V(root_->child(gm_[i].enc));
             std::sort(gm_, gm_ + k_, Greater);
@@ -811,9 +871,13 @@ class GumbelSearch {
         cand_ = 0;
         ++visit_num_;
       }
-      if (visit_num_ >= visits_per_action_) { CloseRound(); continue; }
+      if (visit_num_ >= visits_per_action_) {
+        if (busy) return Loop::kWait;
+        CloseRound();
+        continue;
+      }
       if (gm_[cand_].enc < 0) { ++cand_; continue; }
-      return true;
+      return Loop::kGo;
     }
   }
   // can_stop_early (gumbel.cc:323-351): with the candidates sorted, no move of the half about to
@@ -856,36 +920,44 @@ class GumbelSearch {
   // one playout for candidate cand_ (gumbel.cc:412-452 + Search :674-727).  Returns true if
   // it stopped at an unevaluated leaf (evaluation requested).
   bool StartVisit() {
+    Visit& v = ring_[(head_ + count_) % kMaxInflight];
     const int a0 = gm_[cand_].enc;
-    search_game_ = root_pos_;
-    search_game_.PlayMove(MoveLoc(a0), color_);
-    TreeNode* child = GetOrCreateChild(root_, a0, search_game_, Opp(color_));
-    path_.clear();
-    path_.push_back(PathEntry{-1, child});
+    ++cand_;   // the loop's cursor moves when a playout is issued; its visit is counted when it completes
+    v.is_root = false;
+    v.a0 = a0;
+    v.game = root_pos_;
+    v.game.PlayMove(MoveLoc(a0), color_);
+    TreeNode* child = GetOrCreateChild(root_, a0, v.game, Opp(color_));
+    v.path.clear();
+    v.path.push_back(PathEntry{-1, child});
     Color c = Opp(color_);
     PuctParams pp;
     pp.enable_var_scaling = p_.nonroot_var_scale_prior_visits >= 0;
     pp.var_scale_prior_visits = pp.enable_var_scaling ? p_.nonroot_var_scale_prior_visits : 0;
-    while (path_.back().node->evaluated && !path_.back().node->is_terminal && !search_game_.IsGameOver()) {
-      TreeNode* node = path_.back().node;
-      int a = PuctTopMove(node, search_game_.board, c, pp);
+    while (v.path.back().node->evaluated && !v.path.back().node->is_terminal && !v.game.IsGameOver()) {
+      TreeNode* node = v.path.back().node;
+      int a = PuctTopMove(node, v.game.board, c, pp);
       if (a < 0) a = kPassEncoding;
-      search_game_.PlayMove(MoveLoc(a), c);
-      TreeNode* nx = GetOrCreateChild(node, a, search_game_, Opp(c));
-      path_.back().action = a;
-      path_.push_back(PathEntry{-1, nx});
+      v.game.PlayMove(MoveLoc(a), c);
+      TreeNode* nx = GetOrCreateChild(node, a, v.game, Opp(c));
+      v.path.back().action = a;
+      v.path.push_back(PathEntry{-1, nx});
       c = Opp(c);
     }
-    leaf_color_ = c;
-    TreeNode* leaf = path_.back().node;
-    if (!leaf->evaluated && !search_game_.IsGameOver()) {
-      eval_game_ = &search_game_;
+    return RequestLeaf(v, c);
+  }
+  // the descent stopped at v.path.back(): true if that leaf needs the network (the playout stays in flight)
+  bool RequestLeaf(Visit& v, Color c) {
+    v.leaf_color = c;
+    TreeNode* leaf = v.path.back().node;
+    if (!leaf->evaluated && !v.game.IsGameOver()) {
+      eval_game_ = &v.game;
       eval_color_ = c;
-      state_ = State::kLeafEvalWait;
+      ++count_;
       return true;
     }
     if (!leaf->evaluated) leaf->evaluated = true;   // terminal leaves carry no policy
-    CompleteVisit();
+    CompleteVisit(v);
     return false;
   }
 
@@ -900,33 +972,26 @@ class GumbelSearch {
     res_.nn_move = MoveLoc(amax);
   }
   bool StartVisitPuct() {
-    search_game_ = root_pos_;
-    path_.clear();
-    path_.push_back(PathEntry{-1, root_});
+    Visit& v = ring_[(head_ + count_) % kMaxInflight];
+    v.is_root = false;
+    v.a0 = -1;
+    v.game = root_pos_;
+    v.path.clear();
+    v.path.push_back(PathEntry{-1, root_});
     Color c = color_;
     bool first = true;
-    while (path_.back().node->evaluated && !path_.back().node->is_terminal && !search_game_.IsGameOver()) {
-      TreeNode* node = path_.back().node;
-      int a = PuctTopMove(node, search_game_.board, c, puct_pp_, first);
+    while (v.path.back().node->evaluated && !v.path.back().node->is_terminal && !v.game.IsGameOver()) {
+      TreeNode* node = v.path.back().node;
+      int a = PuctTopMove(node, v.game.board, c, puct_pp_, first);
       first = false;
       if (a < 0) a = kPassEncoding;
-      search_game_.PlayMove(MoveLoc(a), c);
-      TreeNode* nx = GetOrCreateChild(node, a, search_game_, Opp(c));
-      path_.back().action = a;
-      path_.push_back(PathEntry{-1, nx});
+      v.game.PlayMove(MoveLoc(a), c);
+      TreeNode* nx = GetOrCreateChild(node, a, v.game, Opp(c));
+      v.path.back().action = a;
+      v.path.push_back(PathEntry{-1, nx});
       c = Opp(c);
     }
-    leaf_color_ = c;
-    TreeNode* leaf = path_.back().node;
-    if (!leaf->evaluated && !search_game_.IsGameOver()) {
-      eval_game_ = &search_game_;
-      eval_color_ = c;
-      state_ = State::kLeafEvalWait;
-      return true;
-    }
-    if (!leaf->evaluated) leaf->evaluated = true;
-    CompleteVisit();
-    return false;
+    return RequestLeaf(v, c);
   }
   void FinishPuct() {
     float counts[kNumMoves] = {};
@@ -959,28 +1024,27 @@ class GumbelSearch {
     res_.kld = 0;
   }
 
-  void CompleteVisit() {
-    TreeNode* leaf = path_.back().node;
-    if (search_game_.IsGameOver() && !leaf->is_terminal) {
-      Scores s = search_game_.GetScores();
-      EvaluateTerminal(s, leaf, leaf_color_, color_, root_->init_score_est, score_util_);
+  void CompleteVisit(Visit& v) {
+    TreeNode* leaf = v.path.back().node;
+    if (v.game.IsGameOver() && !leaf->is_terminal) {
+      Scores s = v.game.GetScores();
+      EvaluateTerminal(s, leaf, v.leaf_color, color_, root_->init_score_est, score_util_);
       leaf->evaluated = true;
     }
-    AssignBiasCacheEntry(bias_cache_, search_game_, leaf);   // gumbel.cc:683,724
-    Backward();
+    AssignBiasCacheEntry(bias_cache_, v.game, leaf);   // gumbel.cc:683,724
+    Backward(v);
     ++visits_spent_;
     if (puct_root_) return;   // the root is part of the path and was updated by Backward
-    root_->edge(gm_[cand_].enc)->visits += 1;
-    ++cand_;
+    root_->edge(v.a0)->visits += 1;
   }
 
-  void Backward() {   // gumbel.cc:738-754
-    TreeNode* leaf = path_.back().node;
+  void Backward(const Visit& v) {   // gumbel.cc:738-754
+    TreeNode* leaf = v.path.back().node;
     const float lq = leaf->init_util_est, lqo = leaf->init_outcome_est, ls = leaf->init_score_est;
-    for (int i = (int)path_.size() - 1; i >= 0; --i) {
-      TreeNode* parent = path_[i].node;
+    for (int i = (int)v.path.size() - 1; i >= 0; --i) {
+      TreeNode* parent = v.path[i].node;
       const float mult = leaf->color_to_move == parent->color_to_move ? 1.0f : -1.0f;
-      SingleBackup(parent, path_[i].action, i == (int)path_.size() - 1, mult * lq, mult * lqo, mult * ls);
+      SingleBackup(parent, v.path[i].action, i == (int)v.path.size() - 1, mult * lq, mult * lqo, mult * ls);
     }
   }
 
@@ -1113,13 +1177,14 @@ class GumbelSearch {
   int theoretical_winner_visits_ = 0;
   uint32_t visits_spent_ = 0;
   bool round_open_ = false;
-  Position root_pos_, search_game_;
+  Position root_pos_;
+  Visit ring_[kMaxInflight];   // playouts in flight, oldest at head_
+  int head_ = 0, count_ = 0;
+  bool have_pending_ = false;
   bool puct_root_ = false;
   PuctParams puct_pp_;
   ScoreUtilityParams score_util_;   // GumbelEvaluator's ScoreUtilityParams (gumbel.h ctor; eval.cc:170,178)
   std::vector<std::pair<int, int>> pre_visits_;
-  std::vector<PathEntry> path_;
-  Color leaf_color_ = kBlack;
   const Position* eval_game_ = nullptr;
   Color eval_color_ = kBlack;
   p3hip_result pending_;

@@ -25,6 +25,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <memory>
 #include <mutex>
@@ -203,22 +204,50 @@ class EvalCache {
     return nullptr;
   }
   void Insert(const Key& k, const p3hip_result& r) {
-    if (cap_ <= 0) return;
-    if ((int)entries_.size() < cap_) {
-      entries_.push_back(Entry{k, ++clock_, r});
-      return;
-    }
-    size_t lru = 0;
-    for (size_t i = 1; i < entries_.size(); ++i)
-      if (entries_[i].stamp < entries_[lru].stamp) lru = i;
-    entries_[lru] = Entry{k, ++clock_, r};
+    if (Entry* e = Victim()) { e->key = k; e->stamp = ++clock_; e->id = 0; e->pending = false; e->result = r; }
+  }
+  // Several evaluations of one game in flight (round 4): a request that misses takes its entry AT ONCE
+  // (InsertPending) and the result is written into it when it arrives (Fill), so every later lookup sees the cache
+  // exactly as the one-at-a-time order Find -> evaluate -> Insert -> Find ... leaves it — the same stamps, the
+  // same entry evicted.  A lookup that finds a reserved entry (kPending) waits for that evaluation; an entry
+  // evicted before its result arrived is simply not filled (the one-at-a-time order would have filled it and
+  // then evicted it).
+  enum class Lookup { kMiss, kHit, kPending };
+  Lookup Probe(const Key& k, const p3hip_result** hit, uint64_t* pending_id) {
+    for (auto& e : entries_)
+      if (e.key == k) {
+        e.stamp = ++clock_;
+        if (e.pending) { *pending_id = e.id; return Lookup::kPending; }
+        *hit = &e.result;
+        return Lookup::kHit;
+      }
+    return Lookup::kMiss;
+  }
+  uint64_t InsertPending(const Key& k) {   // 0: no cache
+    Entry* e = Victim();
+    if (!e) return 0;
+    e->key = k; e->stamp = ++clock_; e->id = ++next_id_; e->pending = true;
+    return e->id;
+  }
+  void Fill(uint64_t id, const p3hip_result& r) {
+    if (!id) return;
+    for (auto& e : entries_)
+      if (e.id == id && e.pending) { e.result = r; e.pending = false; return; }
   }
   void Clear() { entries_.clear(); }
 
  private:
-  struct Entry { Key key; uint64_t stamp; p3hip_result result; };
+  struct Entry { Key key; uint64_t stamp = 0, id = 0; bool pending = false; p3hip_result result; };
+  Entry* Victim() {   // the entry an insertion takes: a fresh one below capacity, else the least recently used
+    if (cap_ <= 0) return nullptr;
+    if ((int)entries_.size() < cap_) { entries_.emplace_back(); return &entries_.back(); }
+    size_t lru = 0;
+    for (size_t i = 1; i < entries_.size(); ++i)
+      if (entries_[i].stamp < entries_[lru].stamp) lru = i;
+    return &entries_[lru];
+  }
   int cap_, nlast_;
-  uint64_t clock_ = 0;
+  uint64_t clock_ = 0, next_id_ = 0;
   std::vector<Entry> entries_;
 };
 
@@ -231,61 +260,114 @@ class GameRunner {
   }
 
   // Advances this game until it needs a network evaluation; writes the features of the
-  // position to evaluate into *f.
+  // position to evaluate into *f.  One evaluation in flight (the reference's order of work).
   void AdvanceToEval(p3hip_features* f) {
+    if (!TryAdvance(f, 1)) {
+      std::fprintf(stderr, "GameRunner::AdvanceToEval: blocked with %zu requests in flight\n", fifo_.size());
+      std::abort();
+    }
+  }
+  // Advances this game until it has a position for the engine (true: *f holds it, the request joins the
+  // in-flight queue) or until nothing more can start before a result in flight arrives (false).  Up to
+  // `max_inflight` playouts of one search wait for results at the same time (GumbelSearch::IssueNext); the
+  // game's moves, its random draws, its cache and every result are those of max_inflight = 1.
+  bool TryAdvance(p3hip_features* f, int max_inflight) {
     for (;;) {
-      if (forking_) {   // the fork manager's candidate evaluations ride in the same batches
+      if (forking_) {   // the fork manager's candidate evaluations ride in the same batches, one at a time
+        if (!fifo_.empty()) return false;
         Color c;
         if (!fork_->NextEval(&side_pos_, &c)) {
           forking_ = false;
           PlayMove();
           continue;
         }
-        side_pending_ = true;
-        if (RequestEval(side_pos_, c, f)) return;
+        if (RequestEval(side_pos_, c, f, true)) return true;
         continue;
       }
-      if (search_.Step() == GumbelSearch::Status::kNeedEval) {
-        if (RequestEval(*search_.eval_game(), search_.eval_color(), f)) return;
+      const GumbelSearch::Issue s = search_.IssueNext(max_inflight);
+      if (s == GumbelSearch::Issue::kNeedEval) {
+        if (RequestEval(*search_.eval_game(), search_.eval_color(), f, false)) return true;
         continue;
       }
+      if (s == GumbelSearch::Issue::kBlocked) return false;
       FinishMove();
     }
   }
+  // the engine's result for the OLDEST request that went to the engine (requests complete in order)
   void DeliverResult(p3hip_result& r) {
-    UnapplySymmetry(sym_, &r);   // nn_interface.h:263-288
-    cache_.Insert(pending_key_, r);   // nn_interface.cc:130
-    Resume(r);
+    Request e = std::move(fifo_.front());
+    fifo_.pop_front();
+    UnapplySymmetry(e.sym, &r);   // nn_interface.h:263-288
+    cache_.Fill(e.cache_id, r);   // nn_interface.cc:130 (the entry was reserved when the request missed)
+    for (Request& w : fifo_)      // requests for the same key made while this one was in flight
+      if (w.alias_of == e.cache_id && w.alias_of != 0 && !w.res) w.res.reset(new p3hip_result(r));
+    Complete(e, r);
+    while (!fifo_.empty() && fifo_.front().res) {
+      Request a = std::move(fifo_.front());
+      fifo_.pop_front();
+      Complete(a, *a.res);
+    }
   }
+  // where the scheduler put the request TryAdvance just returned, and the slot of the oldest request if it went
+  // to `lane` (-1 otherwise)
+  void SetBackSlot(int lane, int slot) { fifo_.back().lane = lane; fifo_.back().slot = slot; }
+  int FrontSlot(int lane) const {
+    return !fifo_.empty() && !fifo_.front().alias_of && fifo_.front().lane == lane ? fifo_.front().slot : -1;
+  }
+  size_t inflight() const { return fifo_.size(); }
   const GameStats& stats() const { return stats_; }
   const Game& game() const { return *game_; }
   // false while the game still samples its opening from the raw policy (one evaluation per move,
   // self_play_thread.cc:44,363-366): the scheduler's advance phase plays every game past it
   bool past_opening() const { return game_->num_moves() >= num_moves_raw_policy_; }
   const std::vector<Move>& last_moves() const { return last_moves_; }
+  uint64_t first_game_digest() const { return first_game_digest_; }   // 0 until the first game has finished
   const Game::Result& last_result() const { return last_result_; }
 
  private:
-  // true: *f holds a position for the engine; false: served from the cache
-  bool RequestEval(const Position& pos, Color c, p3hip_features* f) {
-    pending_key_ = cache_.MakeKey(pos, c);
-    if (const p3hip_result* hit = cache_.Find(pending_key_)) {   // nn_interface.cc:112-118
-      ++stats_.cache_hits;
-      Resume(*hit);
-      return false;
+  struct Request {
+    Symmetry sym = kIdentity;
+    uint64_t cache_id = 0;    // the cache entry reserved for the result (0: none)
+    uint64_t alias_of = 0;    // != 0: no engine request of its own, waits for the request that owns this entry
+    bool side = false;        // a fork candidate's evaluation (ForkManager), not the search's
+    int lane = -1, slot = -1;
+    std::unique_ptr<p3hip_result> res;   // an alias's result, once its owner's has arrived
+  };
+  // true: *f holds a position for the engine; false: served from the cache (now, or when the evaluation of the
+  // same key that is already in flight arrives)
+  bool RequestEval(const Position& pos, Color c, p3hip_features* f, bool side) {
+    const EvalCache::Key key = cache_.MakeKey(pos, c);
+    const p3hip_result* hit = nullptr;
+    uint64_t owner = 0;
+    switch (cache_.Probe(key, &hit, &owner)) {   // nn_interface.cc:112-118
+      case EvalCache::Lookup::kHit:
+        ++stats_.cache_hits;
+        if (side) fork_->Deliver(*hit);
+        else search_.ResolveBack(*hit);
+        return false;
+      case EvalCache::Lookup::kPending: {
+        ++stats_.cache_hits;
+        Request w;
+        w.alias_of = owner;
+        w.side = side;
+        fifo_.push_back(std::move(w));
+        return false;
+      }
+      case EvalCache::Lookup::kMiss:
+        break;
     }
-    sym_ = RandomSymmetry(prob_.prng());   // nn_interface.cc:123
-    FillFeatures(pos, c, sym_, f);
+    Request e;
+    e.sym = RandomSymmetry(prob_.prng());   // nn_interface.cc:123
+    FillFeatures(pos, c, e.sym, f);
     ++stats_.evals;
+    e.cache_id = cache_.InsertPending(key);
+    e.side = side;
+    fifo_.push_back(std::move(e));
     return true;
   }
-  void Resume(const p3hip_result& r) {
-    if (side_pending_) {
-      side_pending_ = false;
-      fork_->Deliver(r);
-    } else {
-      search_.Resume(r);
-    }
+  void Complete(const Request& e, const p3hip_result& r) {
+    if (e.side) fork_->Deliver(r);
+    else search_.Deliver(r);
   }
 
   void NewGame() {   // self_play_thread.cc:319-426
@@ -326,7 +408,8 @@ class GameRunner {
     fork_.reset();
     if (cfg_.init_state_sampling && cfg_.reuse)
       fork_.reset(new ForkManager(cfg_.fork_params, cfg_.reuse, prob_, /*started_from_forced_search=*/!is_fresh_game));
-    forking_ = side_pending_ = false;
+    forking_ = false;
+    fifo_.clear();
     cache_.Clear();
     if (game_->IsGameOver() || game_->num_moves() >= cfg_.max_moves) {
       // A restart state can already be finished (a fork whose alternative move was the second
@@ -344,6 +427,14 @@ class GameRunner {
     if (game_->result().winner == kBlack) ++stats_.black_wins;
     last_result_ = game_->result();
     last_moves_ = game_->moves();
+    if (stats_.games == 1) {   // a digest of this runner's first game: schedules are compared by it (tests)
+      uint64_t d = 0xcbf29ce484222325ull;
+      for (const Move& m : last_moves_) d = (d ^ (uint64_t)(MoveIdx(m.loc) * 4 + (int)m.color + 2)) * 0x100000001b3ull;
+      uint32_t bs, ws;
+      std::memcpy(&bs, &last_result_.bscore, 4);
+      std::memcpy(&ws, &last_result_.wscore, 4);
+      first_game_digest_ = ((d ^ bs) * 0x100000001b3ull ^ ws) * 0x100000001b3ull | 1;
+    }
     if (fork_) fork_->FinalizeGame(*game_, prob_);
     if (cfg_.recorder) cfg_.recorder->RecordGame(init_board_, *game_, std::move(move_infos_));
     NewGame();
@@ -511,21 +602,21 @@ class GameRunner {
   Color color_ = kBlack;
   Loc move_ = kNoopLoc;
   GumbelSearch search_;
-  Symmetry sym_ = kIdentity;
   int num_moves_raw_policy_ = 0, fast_move_gumbel_k_ = 4, num_consecutive_down_bad_moves_ = 0;
   float fast_move_noise_scaling_ = 1.0f, fast_move_root_fpu_ = 0.0f;
   bool use_puct_fast_search_ = false, force_full_search_first_move_ = false;
-  bool forking_ = false, side_pending_ = false;
+  bool forking_ = false;
+  std::deque<Request> fifo_;   // evaluation requests in flight, oldest first
   std::unique_ptr<ForkManager> fork_;
   Position side_pos_;
   PreSearch pre_;
   std::vector<MoveSearchRecord> move_infos_;
   EvalCache cache_;
   MoveSelManager move_sel_;
-  EvalCache::Key pending_key_{};
   GameStats stats_;
   Game::Result last_result_;
   std::vector<Move> last_moves_;
+  uint64_t first_game_digest_ = 0;
 };
 
 // ---- scheduler -----------------------------------------------------------------------------
@@ -595,17 +686,38 @@ class WorkerPool {
   bool stop_ = false;
 };
 
-// One game group: its engine instance, its games, and the driver thread that alternates
-// "evaluate the group's leaves" (Evaluator::Run: H2D, forward pass, D2H on the group's stream) and
-// "advance every game to its next leaf" (a ParallelFor on the shared pool).
-struct Half {
+// One game group: its games and its LANES.  A lane is an engine instance with its own stream and a driver
+// thread that alternates "evaluate the lane's batch" (Evaluator::Run: H2D, forward pass, D2H) and the lane's host
+// phase "hand its results to the games, advance every game to its next leaf, load the leaves" (ParallelFors on the
+// shared pool).  With one lane (the default) host and GPU alternate within the group and it is the other groups
+// that keep the GPU busy.  With two, the host phases of the lanes alternate — while one lane's batch is on the GPU
+// the other lane's results are consumed and its next batch is filled — which needs games that can have leaves in
+// both batches at once: GameRunner::TryAdvance with several playouts in flight.
+struct Lane {
   std::unique_ptr<Evaluator> eval;
+  std::thread driver;
+  std::atomic<int> count{0};   // slots loaded for the next run
+  // written in the lane's host phase, read by its accounting after the run that evaluated that batch
+  GameStats delta;             // game counters added by the host phase that loaded the batch
+  double host_seconds = 0;
+  bool in_opening = false;     // some game still samples its opening from the raw policy
+  long past_opening = 0;
+};
+struct Half {
+  std::vector<std::unique_ptr<Lane>> lanes;
   std::vector<std::unique_ptr<GameRunner>> games;
   std::vector<p3hip_features> feats;
-  std::thread driver;
-  // written by the driver thread only; read by the caller after the thread has been joined
-  bool ok = true;
-  double gpu_seconds = 0, host_seconds = 0;   // inside Run / inside advance, measured region only
+  // whose host phase is next (the lanes' host phases alternate strictly, so a game's results arrive in request order)
+  std::mutex turn_mu;
+  std::condition_variable turn_cv;
+  int turn = 0;
+  bool quit = false;
+  GameStats prev;              // game counters at the end of the last host phase (host phases only)
+  // guarded by the job's clock mutex; read by the caller after the threads have been joined
+  bool ok = true, ready = false;
+  long warm = 0;
+  int adv_left = 0;
+  double gpu_seconds = 0, host_seconds = 0;   // inside Run / inside the host phases, measured region only
   long measured_batches = 0;
   GameStats counted;                           // game counters summed over the measured batches
   long advance_batches = 0, past_opening_at_start = 0;
@@ -627,6 +739,8 @@ long g_last_bias_pruned = 0;
 double g_last_bias_adj = 0;
 int g_num_groups = 2;
 long g_step_limit = 0;   // > 0: the measured region ends after this many engine batches
+int g_num_lanes = 1, g_max_inflight = 1;
+std::vector<uint64_t> g_first_game_digests;   // of the last p3host_selfplay_run, one per game runner
 long g_step_rounds = 0;  // > 0: the measured region is this many ROUNDS (one batch of every group), anchored on one group
 int g_advance_limit = 0;   // > 0: untimed batches per group, at most, to play every game past its raw-policy opening
 long g_last_reuse_added = 0, g_last_examples = 0;
@@ -662,6 +776,13 @@ double p3host_selfplay_last_bias_adj() { return g_last_bias_adj; }
 // groups up to G - 1 forward passes are in flight while one group is on the host (one group:
 // host and GPU alternate, BASELINE configs[2] as written).
 void p3host_selfplay_set_groups(int n) { g_num_groups = n < 1 ? 1 : (n > 8 ? 8 : n); }
+// Lanes per game group (engine instances whose batches the group's games fill in turn) and how many playouts of one
+// search may wait for results at once.  1 / 1 (the default): host and GPU alternate within a group.  2 / up to 4:
+// one group overlaps its host work with its own forward passes (BASELINE configs[2] as stated: 1024 games, batch 1024).
+void p3host_selfplay_set_lanes(int lanes, int max_inflight) {
+  g_num_lanes = lanes < 1 ? 1 : (lanes > 2 ? 2 : lanes);
+  g_max_inflight = max_inflight < 1 ? 1 : (max_inflight > GumbelSearch::kMaxInflight ? GumbelSearch::kMaxInflight : max_inflight);
+}
 // > 0: subsequent p3host_selfplay_run calls measure exactly `batches` engine batches (bench.py's
 // --steps), whichever groups they fall in, instead of running for `seconds`; 0 restores the time limit.
 void p3host_selfplay_set_step_limit(long batches) { g_step_limit = batches > 0 ? batches : 0; }
@@ -678,6 +799,13 @@ void p3host_selfplay_set_step_rounds(long rounds) { g_step_rounds = rounds > 0 ?
 void p3host_selfplay_set_advance_limit(int max_batches) { g_advance_limit = max_batches > 0 ? max_batches : 0; }
 // reuse-buffer insertions and training examples written by the last p3host_selfplay_run
 long p3host_selfplay_last_reuse_added() { return g_last_reuse_added; }
+// per game runner of the last p3host_selfplay_run (group by group): a digest of its first finished game, 0 if none
+int p3host_selfplay_last_first_game_digests(uint64_t* out, int cap) {
+  int n = 0;
+  for (uint64_t d : g_first_game_digests)
+    if (n < cap) out[n++] = d;
+  return (int)g_first_game_digests.size();
+}
 long p3host_selfplay_last_examples() { return g_last_examples; }
 
 // Enables game recording for subsequent p3host_selfplay_run calls (dir == "" disables):
@@ -752,19 +880,26 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     cfg.recorder = recorder.get();
   }
   const int NG = g_num_groups;
+  const int NL = g_num_lanes;
+  const int depth = NL > 1 ? g_max_inflight : 1;   // playouts of one search in flight
   if (num_games < NG) num_games = NG;
   std::vector<Half> halves(NG);
   const bool use_null = !engine_lib || !engine_lib[0];
   for (int h = 0; h < NG; ++h) {
     const int ng = num_games / NG + (h < num_games % NG ? 1 : 0);
-    if (use_null) {
-      halves[h].eval.reset(new NullEvaluator());
-    } else {
-      auto* e = new HipEvaluator();
-      halves[h].eval.reset(e);
-      if (!e->Open(engine_lib, weights, ng, device, P3HIP_FLAG_SHARED_DEVICE)) {   // one engine per game group, all on this GPU
-        if (err) snprintf(err, 256, "%s", e->err.c_str());
-        return 1;
+    for (int l = 0; l < NL; ++l) {
+      halves[h].lanes.emplace_back(new Lane());
+      if (use_null) {
+        halves[h].lanes[l]->eval.reset(new NullEvaluator());
+      } else if (!std::strcmp(engine_lib, "hash")) {   // tests: position-dependent results without a network
+        halves[h].lanes[l]->eval.reset(new HashEvaluator(ng));
+      } else {
+        auto* e = new HipEvaluator();
+        halves[h].lanes[l]->eval.reset(e);
+        if (!e->Open(engine_lib, weights, ng, device, P3HIP_FLAG_SHARED_DEVICE)) {   // one engine per lane, all on this GPU
+          if (err) snprintf(err, 256, "%s", e->err.c_str());
+          return 1;
+        }
       }
     }
     for (int g = 0; g < ng; ++g) {
@@ -776,18 +911,6 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   WorkerPool pool(num_threads > 0 ? num_threads : 1);
   for (int h = 0; h < NG; ++h) halves[h].feats.resize(halves[h].games.size());
 
-  auto advance_half = [&](int h, bool deliver) {
-    Half& H = halves[h];
-    pool.ParallelFor((int)H.games.size(), [&H, deliver](int g) {
-      if (deliver) {
-        p3hip_result r;
-        H.eval->Get(g, r);
-        H.games[g]->DeliverResult(r);
-      }
-      H.games[g]->AdvanceToEval(&H.feats[g]);
-      H.eval->Load(g, H.feats[g]);
-    });
-  };
   auto group_totals = [](const Half& H) {
     GameStats t;
     for (auto& g : H.games) {
@@ -798,6 +921,43 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
       t.bias_adj_abs_sum += g->stats().bias_adj_abs_sum;
     }
     return t;
+  };
+  // The host phase of lane `l` of group `h` (the caller holds the group's turn): every game takes its results of
+  // the lane's last run, in request order, and advances to its next leaf, which goes into the lane's next batch.
+  // With several playouts in flight a game may have nothing to start (its next playout waits for a result of the
+  // OTHER lane's batch); the rows such games leave empty go, in a second pass, to games that can start another
+  // playout, so the batch stays full.
+  auto host_phase = [&](int h, int l) {
+    Half& H = halves[h];
+    Lane& L = *H.lanes[l];
+    const int cap = (int)H.games.size();
+    L.count.store(0);
+    pool.ParallelFor(cap, [&H, &L, l, depth](int g) {
+      GameRunner& G = *H.games[g];
+      for (int slot; (slot = G.FrontSlot(l)) >= 0;) {
+        p3hip_result r;
+        L.eval->Get(slot, r);
+        G.DeliverResult(r);
+      }
+      if (G.TryAdvance(&H.feats[g], depth)) {
+        const int slot = L.count.fetch_add(1);
+        L.eval->Load(slot, H.feats[g]);
+        G.SetBackSlot(l, slot);
+      }
+    });
+    if (depth > 1 && L.count.load() < cap) {
+      std::atomic<int> spare{cap - L.count.load()};
+      pool.ParallelFor(cap, [&H, &L, &spare, l, depth](int g) {
+        GameRunner& G = *H.games[g];
+        while (spare.load(std::memory_order_relaxed) > 0) {
+          if (spare.fetch_sub(1) <= 0) { spare.fetch_add(1); break; }
+          if (!G.TryAdvance(&H.feats[g], depth)) { spare.fetch_add(1); break; }
+          const int slot = L.count.fetch_add(1);
+          L.eval->Load(slot, H.feats[g]);
+          G.SetBackSlot(l, slot);
+        }
+      });
+    }
   };
 
   // Every group runs on its own: advance batches (until its games are past their openings), warm-up
@@ -812,85 +972,110 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   const bool by_rounds = round_limit > 0;
   const bool by_steps = !by_rounds && g_step_limit > 0;
   const long step_limit = g_step_limit;
-  const int advance_limit = g_advance_limit;
   std::mutex clock_mu;
   int phase = 0, groups_ready = 0;   // 0 advance + warm-up, 1 measuring, 2 over (guarded by clock_mu)
-  int anchor = -1;                   // by_rounds: the group whose completions open and close the window
+  int anchor = -1, anchor_lane = 0;  // by_rounds: the group (and lane) whose completions open and close the window
   long counted = 0, anchor_rounds = 0;
   std::chrono::steady_clock::time_point t0{}, t1{};
   // completion instants, seconds since t0 (guarded by clock_mu): of the counted batches, or (by_rounds) of the anchor's
   std::vector<double> done_at;
   std::atomic<bool> failed{false};
   for (int h = 0; h < NG; ++h) {
-    halves[h].driver = std::thread([&, h] {
-      Half& H = halves[h];
-      advance_half(h, false);
-      long warm = 0;
-      bool ready = false;
-      int adv_left = advance_limit;
-      double last_host = 0;
-      GameStats prev = group_totals(H);
-      for (;;) {
-        const auto r0 = std::chrono::steady_clock::now();
-        const bool ok = H.eval->Run();
-        const auto r1 = std::chrono::steady_clock::now();
-        // here the group's games are quiescent (results not yet delivered): counters can be read
-        if (!ok) { H.ok = false; failed.store(true); }
-        const GameStats now = group_totals(H);
-        bool over = false;
-        {
-          std::lock_guard<std::mutex> l(clock_mu);
-          // a run belongs to the window by its completion instant, not by when this thread got the lock: r1 is taken
-          // before the lock, so a run that completed before the window opened (or after it closed) can arrive here
-          // with the phase already changed
-          const bool inside = r1 > t0 && (phase == 1 || (phase == 2 && by_rounds && r1 <= t1));
-          if (inside && phase != 0) {
-            ++H.measured_batches;
-            ++counted;
-            H.counted.moves += now.moves - prev.moves; H.counted.games += now.games - prev.games;
-            H.counted.evals += now.evals - prev.evals; H.counted.black_wins += now.black_wins - prev.black_wins;
-            H.counted.cache_hits += now.cache_hits - prev.cache_hits;
-            H.counted.bias_entries_pruned += now.bias_entries_pruned - prev.bias_entries_pruned;
-            H.counted.bias_adj_abs_sum += now.bias_adj_abs_sum - prev.bias_adj_abs_sum;
-            H.gpu_seconds += std::chrono::duration<double>(r1 - r0).count();
-            H.host_seconds += last_host;
-            if (phase == 1) {
-              bool enough;
-              if (by_rounds) {
-                if (h == anchor) { ++anchor_rounds; done_at.push_back(std::chrono::duration<double>(r1 - t0).count()); }
-                enough = h == anchor && anchor_rounds >= round_limit;
-              } else {
-                done_at.push_back(std::chrono::duration<double>(r1 - t0).count());
-                enough = by_steps ? counted >= step_limit : std::chrono::duration<double>(r1 - t0).count() >= seconds;
-              }
-              if (enough) { phase = 2; t1 = r1; }
-            }
-          } else if (phase == 0 && !ready) {
-            bool in_opening = false;
-            if (adv_left > 0) {
-              for (auto& g : H.games)
-                if (!g->past_opening()) { in_opening = true; break; }
-            }
-            if (in_opening) { --adv_left; ++H.advance_batches; }
-            else { adv_left = 0; ++warm; }
-            if (warm >= warmup_batches || failed.load()) {
-              ready = true;
-              for (auto& g : H.games) H.past_opening_at_start += g->past_opening();
-              if (++groups_ready == NG) { phase = failed.load() ? 2 : 1; t0 = t1 = r1; anchor = h; }
-            }
-          }
-          if (phase == 1 && failed.load()) { phase = 2; t1 = r1; }
-          over = phase == 2;
-        }
-        if (over) break;
-        prev = now;
-        const auto a0 = std::chrono::steady_clock::now();
-        advance_half(h, true);
-        last_host = std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
-      }
-    });
+    halves[h].adv_left = g_advance_limit;
+    halves[h].prev = group_totals(halves[h]);
   }
-  for (auto& H : halves) H.driver.join();
+  for (int h = 0; h < NG; ++h)
+    for (int l = 0; l < NL; ++l) {
+      halves[h].lanes[l]->driver = std::thread([&, h, l] {
+        Half& H = halves[h];
+        Lane& L = *H.lanes[l];
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> tl(H.turn_mu);
+            H.turn_cv.wait(tl, [&] { return H.turn == l || H.quit; });
+            if (H.quit) break;
+          }
+          const auto a0 = std::chrono::steady_clock::now();
+          host_phase(h, l);
+          {   // the games are quiescent until the turn is passed on: their counters can be read
+            const GameStats now = group_totals(H);
+            L.delta.moves = now.moves - H.prev.moves; L.delta.games = now.games - H.prev.games;
+            L.delta.evals = now.evals - H.prev.evals; L.delta.black_wins = now.black_wins - H.prev.black_wins;
+            L.delta.cache_hits = now.cache_hits - H.prev.cache_hits;
+            L.delta.bias_entries_pruned = now.bias_entries_pruned - H.prev.bias_entries_pruned;
+            L.delta.bias_adj_abs_sum = now.bias_adj_abs_sum - H.prev.bias_adj_abs_sum;
+            H.prev = now;
+            L.past_opening = 0;
+            for (auto& g : H.games) L.past_opening += g->past_opening();
+            L.in_opening = L.past_opening < (long)H.games.size();
+          }
+          L.host_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
+          {
+            std::lock_guard<std::mutex> tl(H.turn_mu);
+            H.turn = (l + 1) % NL;
+          }
+          H.turn_cv.notify_all();
+          const auto r0 = std::chrono::steady_clock::now();
+          const bool ok = L.eval->Run();
+          const auto r1 = std::chrono::steady_clock::now();
+          if (!ok) failed.store(true);
+          bool over = false;
+          {
+            std::lock_guard<std::mutex> cl(clock_mu);
+            if (!ok) H.ok = false;
+            // a run belongs to the window by its completion instant, not by when this thread got the lock: r1 is taken
+            // before the lock, so a run that completed before the window opened (or after it closed) can arrive here
+            // with the phase already changed
+            const bool inside = r1 > t0 && (phase == 1 || (phase == 2 && by_rounds && r1 <= t1));
+            if (inside && phase != 0) {
+              ++H.measured_batches;
+              ++counted;
+              H.counted.moves += L.delta.moves; H.counted.games += L.delta.games;
+              H.counted.evals += L.delta.evals; H.counted.black_wins += L.delta.black_wins;
+              H.counted.cache_hits += L.delta.cache_hits;
+              H.counted.bias_entries_pruned += L.delta.bias_entries_pruned;
+              H.counted.bias_adj_abs_sum += L.delta.bias_adj_abs_sum;
+              H.gpu_seconds += std::chrono::duration<double>(r1 - r0).count();
+              H.host_seconds += L.host_seconds;
+              if (phase == 1) {
+                bool enough;
+                if (by_rounds) {
+                  // a round = one batch of every lane of every group; the anchor is ONE lane's completions
+                  const bool mine = h == anchor && l == anchor_lane;
+                  if (mine) { ++anchor_rounds; done_at.push_back(std::chrono::duration<double>(r1 - t0).count()); }
+                  enough = mine && anchor_rounds >= round_limit;
+                } else {
+                  done_at.push_back(std::chrono::duration<double>(r1 - t0).count());
+                  enough = by_steps ? counted >= step_limit : std::chrono::duration<double>(r1 - t0).count() >= seconds;
+                }
+                if (enough) { phase = 2; t1 = r1; }
+              }
+            } else if (phase == 0 && !H.ready) {
+              const bool in_opening = H.adv_left > 0 && L.in_opening;
+              if (in_opening) { --H.adv_left; ++H.advance_batches; }
+              else { H.adv_left = 0; ++H.warm; }
+              if (H.warm >= warmup_batches || failed.load()) {
+                H.ready = true;
+                H.past_opening_at_start = L.past_opening;
+                if (++groups_ready == NG) { phase = failed.load() ? 2 : 1; t0 = t1 = r1; anchor = h; anchor_lane = l; }
+              }
+            }
+            if (phase == 1 && failed.load()) { phase = 2; t1 = r1; }
+            over = phase == 2;
+          }
+          if (over) {
+            {
+              std::lock_guard<std::mutex> tl(H.turn_mu);
+              H.quit = true;
+            }
+            H.turn_cv.notify_all();
+            break;
+          }
+        }
+      });
+    }
+  for (auto& H : halves)
+    for (auto& L : H.lanes) L->driver.join();
   int rc = 0;
   for (auto& H : halves)
     if (!H.ok) {
@@ -898,6 +1083,9 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
       if (err) snprintf(err, 256, "engine run failed");
     }
   if (recorder) recorder->Flush();
+  g_first_game_digests.clear();
+  for (auto& H : halves)
+    for (auto& g : H.games) g_first_game_digests.push_back(g->first_game_digest());
   g_last_reuse_added = reuse->added();
   g_last_examples = recorder ? recorder->examples() : 0;
   if (out) {
@@ -1039,6 +1227,130 @@ int p3host_selfplay_one_game(const char* engine_lib, const char* weights, int de
   g_last_bias_pruned = g.stats().bias_entries_pruned;
   g_last_bias_adj = g.stats().bias_adj_abs_sum;
   return n_out;
+}
+
+// Test hook for the evaluation cache's reserve-then-fill protocol: `nreq` lookups over `nkeys` distinct keys,
+// once in the one-at-a-time order (Find, on a miss Insert before the next lookup) and once with up to `depth`
+// results outstanding (Probe, on a miss InsertPending at once and Fill `depth` - 1 lookups later).  Returns the
+// number of lookups the two orders classify differently (hit / miss; a lookup that finds a reserved entry counts
+// as the hit it would have been) or answer with a different result, plus 1000000 if the final contents differ.
+long p3host_test_eval_cache_pipeline(int capacity, int nkeys, int nreq, int depth, uint64_t seed) {
+  EvalCache seq(capacity), pipe(capacity);
+  auto key_of = [](int k) {
+    EvalCache::Key key{0x1234567ull * (uint64_t)(k + 1), {kNoopLoc, kNoopLoc, kNoopLoc, kNoopLoc, kNoopLoc}, 7.5f, kBlack};
+    return key;
+  };
+  auto result_of = [](int k) {
+    p3hip_result r;
+    std::memset(&r, 0, sizeof r);
+    r.err2_outcome = (float)k;
+    return r;
+  };
+  struct Outstanding { uint64_t id; int key; int due; };
+  std::deque<Outstanding> out;
+  long diff = 0;
+  uint64_t x = seed | 1;
+  for (int i = 0; i < nreq; ++i) {
+    while (!out.empty() && out.front().due <= i) {
+      pipe.Fill(out.front().id, result_of(out.front().key));
+      out.pop_front();
+    }
+    x = HashEvaluator::Mix(x);
+    const int k = (int)(x % (uint64_t)nkeys);
+    const p3hip_result* a = seq.Find(key_of(k));
+    if (!a) seq.Insert(key_of(k), result_of(k));
+    const p3hip_result* b = nullptr;
+    uint64_t owner = 0;
+    const EvalCache::Lookup lk = pipe.Probe(key_of(k), &b, &owner);
+    if (lk == EvalCache::Lookup::kMiss) {
+      const uint64_t id = pipe.InsertPending(key_of(k));
+      out.push_back({id, k, i + 1 + (int)((x >> 20) % (uint64_t)depth)});
+      std::stable_sort(out.begin(), out.end(), [](const Outstanding& p, const Outstanding& q) { return p.due < q.due; });
+    }
+    const bool hit_seq = a != nullptr, hit_pipe = lk != EvalCache::Lookup::kMiss;
+    if (hit_seq != hit_pipe) ++diff;
+    else if (a && a->err2_outcome != (float)k) ++diff;
+    else if (lk == EvalCache::Lookup::kHit && b->err2_outcome != (float)k) ++diff;
+    else if (lk == EvalCache::Lookup::kPending) {
+      bool owned = false;
+      for (const Outstanding& o : out) owned |= o.id == owner && o.key == k;
+      if (!owned) ++diff;
+    }
+  }
+  for (const Outstanding& o : out) pipe.Fill(o.id, result_of(o.key));
+  for (int k = 0; k < nkeys; ++k) {   // same contents (these lookups stamp both caches alike)
+    const p3hip_result* a = seq.Find(key_of(k));
+    const p3hip_result* b = pipe.Find(key_of(k));
+    if ((a != nullptr) != (b != nullptr) || (a && a->err2_outcome != b->err2_outcome)) return diff + 1000000;
+  }
+  return diff;
+}
+
+// Test hook for several playouts in flight (GameRunner::TryAdvance): plays `num_games` consecutive games of ONE
+// game runner over the hash evaluator, with up to `depth` evaluation requests outstanding and the results handed
+// back late — a result is delivered when nothing more can start, or earlier on a coin flip of `sched_seed`.
+// out[0] = a digest of every finished game's moves and result, out[1] = evaluations, out[2] = cache hits,
+// out[3] = moves, out[4] = the largest number of requests that were outstanding at once.
+// depth 1 is the one-at-a-time order; every depth and every schedule must return the same out[0..3].
+int p3host_test_game_inflight(int default_n, int default_k, int selected_n, int selected_k, int max_moves, uint64_t seed,
+                              int depth, int num_games, int cache_entries, int init_state_sampling, int early_stopping,
+                              uint64_t sched_seed, uint64_t* out) {
+  SelfPlayConfig cfg;
+  cfg.default_n = default_n; cfg.default_k = default_k;
+  cfg.selected_n = selected_n; cfg.selected_k = selected_k;
+  cfg.max_moves = max_moves;
+  cfg.cache_entries_per_game = cache_entries;
+  cfg.init_state_sampling = init_state_sampling != 0;
+  cfg.early_stopping_enabled = early_stopping != 0;
+  cfg.bias_cache_lambda = g_bias_cache_lambda;
+  cfg.bias_cache_alpha = g_bias_cache_alpha;
+  cfg.sel_mult_base = g_sel_mult_base;
+  cfg.fork_params = ForkParams::ForReuse(g_use_seen_state_prob);
+  auto reuse = std::make_unique<ReuseBuffer>(seed ^ 0x676f6578706c6f69ull);
+  cfg.reuse = reuse.get();
+  GameRunner g(cfg, seed);
+  std::deque<p3hip_result> queue;   // results of the outstanding requests, oldest first
+  uint64_t digest = 0xcbf29ce484222325ull, sched = sched_seed | 1, max_out = 0;
+  long folded = 0;
+  GameStats at_fold;   // counters when the last game finished (the next game's first request included, at every depth)
+  auto fold = [&] {
+    while (folded < g.stats().games) {   // (a finished game's record is replaced when the next one finishes)
+      for (const Move& m : g.last_moves())
+        digest = (digest ^ (uint64_t)(MoveIdx(m.loc) * 4 + (int)m.color + 2)) * 0x100000001b3ull;
+      uint32_t bs, ws;
+      const float b = g.last_result().bscore, w = g.last_result().wscore;
+      std::memcpy(&bs, &b, 4);
+      std::memcpy(&ws, &w, 4);
+      digest = (digest ^ bs) * 0x100000001b3ull;
+      digest = (digest ^ ws) * 0x100000001b3ull;
+      ++folded;
+      at_fold = g.stats();
+    }
+  };
+  p3hip_features f;
+  std::memset(&f, 0, sizeof f);   // FillFeatures writes every field; the hash also covers the padding
+  while (g.stats().games < num_games) {
+    sched = HashEvaluator::Mix(sched);
+    const bool try_issue = queue.empty() || (sched & 3) != 0;
+    if (try_issue && g.TryAdvance(&f, depth)) {
+      queue.emplace_back();
+      HashEvaluator::Evaluate(f, queue.back());
+      max_out = std::max<uint64_t>(max_out, queue.size());
+      fold();
+      continue;
+    }
+    fold();
+    if (queue.empty()) return 1;   // blocked with nothing outstanding: a scheduling bug
+    g.DeliverResult(queue.front());
+    queue.pop_front();
+    fold();
+  }
+  out[0] = digest;
+  out[1] = (uint64_t)at_fold.evals;
+  out[2] = (uint64_t)at_fold.cache_hits;
+  out[3] = (uint64_t)at_fold.moves;
+  out[4] = max_out;
+  return 0;
 }
 
 }  // extern "C"

@@ -145,7 +145,7 @@ def selfplay_run(weights: str | None, num_games: int, num_threads: int, seconds:
     st = SelfPlayStats()
     err = C.create_string_buffer(256)
     if weights is None:
-        elib = None
+        elib = engine_lib.encode() if engine_lib == "hash" else None   # "hash": HashEvaluator, position-dependent test results
     else:
         elib = (engine_lib or os.path.join(_HERE, "csrc", "libp3hip.so")).encode()
     rc = L.p3host_selfplay_run(elib, weights.encode() if weights else None, device, num_games, num_threads,
@@ -262,6 +262,26 @@ def set_groups(n: int) -> None:
     L = lib()
     L.p3host_selfplay_set_groups.argtypes = [C.c_int]
     L.p3host_selfplay_set_groups(n)
+
+
+def set_lanes(lanes: int = 1, max_inflight: int = 1) -> None:
+    """Lanes per game group (engine instances whose batches the group's games fill in turn) and how many playouts of
+    one search may wait for results at once (GumbelSearch::IssueNext; at most 4).  1 / 1, the default: host and GPU
+    alternate within a group.  2 / 4: one group overlaps its host work with its own forward passes — BASELINE
+    configs[2] as stated (1024 games, batch 1024) without a second game group.  The games are the same either way."""
+    L = lib()
+    L.p3host_selfplay_set_lanes.argtypes = [C.c_int, C.c_int]
+    L.p3host_selfplay_set_lanes(int(lanes), int(max_inflight))
+
+
+def last_first_game_digests() -> np.ndarray:
+    """Per game runner of the last selfplay_run: a digest of its first finished game (moves and score), 0 if none."""
+    L = lib()
+    L.p3host_selfplay_last_first_game_digests.argtypes = [C.c_void_p, C.c_int]
+    n = L.p3host_selfplay_last_first_game_digests(None, 0)
+    out = np.zeros(max(n, 1), np.uint64)
+    L.p3host_selfplay_last_first_game_digests(out.ctypes.data, n)
+    return out[:n]
 
 
 def set_advance_limit(max_batches: int) -> None:

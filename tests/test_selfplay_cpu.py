@@ -599,3 +599,95 @@ def test_opening_book_start(host):
             assert moves[0] == 3 * 19 + 3
         lens.add(nm)
     assert lens == {0, 1, 2, 3, 4}
+
+
+def _inflight(host, seed, depth, sched, n=32, k=5, sn=32, sk=5, max_moves=60, games=3, cache=64, init=1, es=0):
+    L = host.lib()
+    f = L.p3host_test_game_inflight
+    f.argtypes = [C.c_int] * 5 + [C.c_uint64] + [C.c_int] * 5 + [C.c_uint64, C.POINTER(C.c_uint64)]
+    out = (C.c_uint64 * 5)()
+    assert f(n, k, sn, sk, max_moves, seed, depth, games, cache, init, es, sched, out) == 0
+    return list(out)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(),                                                                  # bench.py's search: n = 32, k = 5
+    dict(n=64, k=8, sn=128, sk=8, max_moves=80, games=2, cache=4, es=1),     # early stopping on, a four-entry cache
+    dict(n=16, k=4, sn=48, sk=6, max_moves=150, games=3, cache=2, init=0),
+    dict(n=8, k=2, sn=8, sk=2, max_moves=300, games=5),                      # two considered actions: every other playout waits
+    dict(n=32, k=5, max_moves=250, games=2, cache=1, es=1),
+])
+def test_playouts_in_flight_play_the_same_games(host, cfg):
+    """Round 4: up to four playouts of one Gumbel search wait for their evaluations at once
+    (GumbelSearch::IssueNext, GameRunner::TryAdvance) so that ONE group of games can fill a second engine batch while
+    its first is on the GPU.  A playout starts early only if no playout in flight shares its considered action and no
+    read of the root children's statistics (a round closing, an early-stopping check) lies in between; the evaluation
+    cache reserves a missed entry at request time.  Over a position-dependent evaluator (HashEvaluator) one game runner
+    plays several consecutive games — restart states, forks, raw-policy openings, PUCT fast moves and tree reuse
+    included — at depth 1 (the reference's order) and at depths 2 and 4 under two result-arrival schedules: the
+    moves, the scores, the number of evaluations and of cache hits must be identical, and requests must really have
+    been outstanding together."""
+    for seed in (11, 12):
+        base = _inflight(host, seed, 1, 1, **cfg)
+        assert base[4] == 1
+        for depth in (2, 4):
+            for sched in (3, 9):
+                got = _inflight(host, seed, depth, sched, **cfg)
+                assert got[:4] == base[:4], (seed, depth, sched)
+                assert got[4] == min(depth, cfg.get("k", 5))
+
+
+def test_playouts_in_flight_are_off_where_playouts_share_state(host):
+    """With a bias cache every playout reads and writes the cache's shared entries, so the search keeps one
+    evaluation in flight whatever depth the scheduler allows (as for a PUCT root and in graph mode)."""
+    host.set_bias_cache(0.3, 0.8)
+    try:
+        base = _inflight(host, 5, 1, 1, max_moves=40, games=1)
+        got = _inflight(host, 5, 4, 3, max_moves=40, games=1)
+    finally:
+        host.set_bias_cache(0.0, 0.8)
+    assert got[:4] == base[:4] and got[4] == 1
+
+
+def test_eval_cache_reserves_a_missed_entry_and_fills_it_later(host):
+    """EvalCache::Probe / InsertPending / Fill against Find / Insert: random lookups over a few keys, once one at a
+    time and once with up to four results outstanding (filled out of order, after their entries may have been
+    evicted): the same lookups hit, with the same results, and the caches end with the same contents — at every
+    capacity from 'evicts on every miss' to 'never evicts', and with the cache off."""
+    f = host.lib().p3host_test_eval_cache_pipeline
+    f.argtypes = [C.c_int] * 4 + [C.c_uint64]
+    f.restype = C.c_long
+    for cap, nkeys, depth in ((1, 3, 2), (2, 5, 4), (4, 6, 3), (8, 12, 4), (64, 80, 4), (3, 3, 4), (0, 4, 2)):
+        for seed in (1, 2, 3):
+            assert f(cap, nkeys, 4000, depth, seed) == 0, (cap, nkeys, depth, seed)
+
+
+def test_two_lanes_of_one_group_play_the_same_games(host):
+    """The scheduler's two-lane form (host_api.set_lanes; BASELINE configs[2] as stated): ONE group of games fills
+    two engine batches in turn — results of one lane are consumed and its next batch is filled while the other
+    lane's batch is being evaluated — with rows left empty by games that have to wait handed to games that can start
+    another playout.  Every game runner's first game is the same as with one lane, for every depth, and with three
+    or more playouts in flight the batches stay (nearly) full where depth 1 leaves every other batch empty."""
+    host.set_policy(init_state_sampling=False)
+    host.set_groups(1)
+
+    def run(lanes, depth, steps):
+        host.set_lanes(lanes, depth)
+        host.set_step_limit(steps)
+        st = host.selfplay_run(None, 48, 4, 0.0, default_n=16, default_k=4, selected_n=16, selected_k=4, max_moves=24,
+                               warmup_batches=1, seed=5, engine_lib="hash")
+        return host.last_first_game_digests(), st.positions / st.batches / 48
+
+    try:
+        base, fill = run(1, 1, 560)
+        assert fill == 1.0 and (base != 0).all()
+        for depth, steps, min_fill in ((1, 1120, 0.49), (2, 800, 0.7), (4, 700, 0.88)):
+            got, fill = run(2, depth, steps)
+            both = (got != 0) & (base != 0)
+            assert both.sum() >= 44 and (got[both] == base[both]).all(), depth
+            assert fill >= min_fill, (depth, fill)
+    finally:
+        host.set_lanes(1, 1)
+        host.set_step_limit(0)
+        host.set_groups(2)
+        host.set_policy()

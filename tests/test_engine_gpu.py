@@ -251,6 +251,35 @@ def test_selfplay_host_on_hip_engine(built, weight_files):
     assert len(mv) > 10 and np.array_equal(mv, mv2)   # deterministic on the GPU too
 
 
+def test_two_lanes_of_one_group_play_the_same_games_on_hip_engines(built, weight_files):
+    """BASELINE configs[2] as stated, scaled down: ONE group of games over two engine instances filled in turn
+    (host_api.set_lanes(2, 4), up to four playouts of a search waiting for results at once) plays, game runner by game
+    runner, the same first game as the same group over one engine with one evaluation in flight — on the GPU, where a
+    position's result must not depend on which batch, row or engine instance evaluated it — and keeps its batches full."""
+    from p3achygo_amd import host_api
+    host_api.set_policy(init_state_sampling=False)
+    host_api.set_groups(1)
+
+    def run(lanes, depth, steps):
+        host_api.set_lanes(lanes, depth)
+        host_api.set_step_limit(steps)
+        st = host_api.selfplay_run(weight_files("test_b3c128btl2"), 96, 4, 0.0, default_n=16, default_k=4, selected_n=16,
+                                   selected_k=4, max_moves=24, warmup_batches=1, seed=5)
+        return host_api.last_first_game_digests(), st.positions / st.batches / 96
+
+    try:
+        base, fill1 = run(1, 1, 600)
+        got, fill2 = run(2, 4, 720)
+    finally:
+        host_api.set_lanes(1, 1)
+        host_api.set_step_limit(0)
+        host_api.set_groups(2)
+        host_api.set_policy()
+    both = (got != 0) & (base != 0)
+    assert both.sum() >= 88 and (got[both] == base[both]).all()
+    assert fill1 == 1.0 and fill2 >= 0.88
+
+
 def test_config_c1_game_with_bias_cache_on_hip_engine(built, weight_files):
     """BASELINE configs[0] on the GPU engine: v4's net (b8c128nbt) and search settings (Gumbel n=8
     k=4, bias_cache_lambda 0.3 / alpha 0.8, config/v4.json), one self-play game on one thread: it

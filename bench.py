@@ -28,7 +28,9 @@ touches the GPU); under torch.distributed.run it checks N against WORLD_SIZE.
 Secondary figures in the same JSON line:
   engine_only  — forward pass alone over a resident batch (no host, no PCIe);
   engine_benchmark — the reference's nn::Benchmark loop (benchmark_engine.cc:77-108) from C++ over the C ABI;
-  as_stated_c3 — BASELINE configs[2] as written: ONE group of 1024 games, batch 1024;
+  as_stated_c3 — BASELINE configs[2] as written: ONE group of 1024 games, batch 1024, the group filling two engine
+                 batches in turn with up to 4 playouts of a game's search in flight (round 4: same games, DESIGN.md
+                 section 5); `one_lane` inside it = host and GPU alternating, the figure of rounds 1-3;
   roofline     — dominant kernel k_block: conv FLOPs (3x3s + 1x1 reduce/expand) per launch / HIP-event
                  time on the engine's stream, against the 2.5 PFLOP/s dense fp16 MFMA peak;
   cpu_baseline — the CPU fp32 oracle on this box's host cores over a bounded sample: engine-only
@@ -49,6 +51,10 @@ import numpy as np  # noqa: E402
 MODEL = "b12c256btl3"
 BATCH = 1024
 DEFAULT_GROUPS = GROUPS = 8          # game groups per GPU: forward passes of the others queued while one group is on the host
+                                     # (round 4: ONE group filling two engine batches in turn — `--groups 1 --lanes 2`, the stated 1024 games
+                                     # — measures 219-225 k where eight one-lane groups measure 220-228 k on the same box; the headline stays
+                                     # at eight groups because one slow game (an exact ladder read-out) stalls a lone group's pipeline and a
+                                     # 20-round window is then 0.2 s long; both are in every line)
                                      # (round 2: 4 / 6 / 8 / 12 groups 217 / 222 / 220 / 220 k positions/s on one box; round 3, the forward
                                      # pass one long launch: 4 / 6 / 8 groups 225 / 237 / 241 k with 241 k engine-only, and the driver's
                                      # 20-step window steadier with eight: 239-242 k against 209-242 k)
@@ -207,7 +213,13 @@ def main():
                     help="timed ROUNDS per GPU: one engine batch (p3hip_run) of every game group each")
     ap.add_argument("--warmup", type=int, default=16, help="untimed warm-up rounds (one batch per game group each)")
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--groups", type=int, default=DEFAULT_GROUPS, help="game groups (engine instances / HIP streams) per GPU")
+    ap.add_argument("--groups", type=int, default=DEFAULT_GROUPS, help="game groups per GPU (each `--batch` games)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="engine instances (HIP streams) per game group, filled in turn by the group's games; 1 (default) = "
+                         "host and GPU alternate within a group and the other groups keep the GPU busy; `--groups 1 --lanes 2` "
+                         "is BASELINE configs[2] as stated, the `as_stated_c3` leg of the default run")
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="playouts of one game's search that may wait for results at once when --lanes > 1")
     ap.add_argument("--model", default=MODEL)
     ap.add_argument("--advance-limit", type=int, default=64,
                     help="untimed batches per group, at most, that play every game past its raw-policy opening "
@@ -272,8 +284,10 @@ def main():
     # ---- headline: self-play through the C ABI ----------------------------------------------
     threads = max(2, min(16, len(cpus)))
     GROUPS = args.groups   # local from here on
+    LANES = max(1, min(4, args.lanes))
     steps = args.steps
     host_api.set_groups(GROUPS)
+    host_api.set_lanes(LANES, args.inflight if LANES > 1 else 1)
     host_api.set_ladder_budget(args.ladder_budget)
     host_api.set_step_rounds(steps)
     host_api.set_advance_limit(args.advance_limit)
@@ -282,12 +296,13 @@ def main():
     sync()
     wall0 = time.perf_counter()
     st = host_api.selfplay_run(path if use_gpu else None, GROUPS * args.batch, threads, 0.0, default_n=32, default_k=5,
-                               selected_n=32, selected_k=5, warmup_batches=args.warmup,
+                               selected_n=32, selected_k=5, warmup_batches=args.warmup * LANES,
                                seed=sharding.seed_for_rank(77, shard), device=local_rank)
     sync()
     wall = time.perf_counter() - wall0
     host_api.set_step_rounds(0)
     host_api.set_advance_limit(0)
+    host_api.set_lanes(1, 1)
     ladder1 = host_api.ladder_stats()
     dt = sharding.max_over_ranks(shard, st.seconds)
     dt_fit = sharding.max_over_ranks(shard, st.seconds_fit)
@@ -307,9 +322,10 @@ def main():
             "config": {"workload": f"{args.model} random-init, self-play: C++ host (Gumbel MCTS n=32, default k<=5, "
                                    f"selected k=5) -> p3hip_run over batches of {args.batch} leaf positions -> "
                                    f"results back to the search; one step = one round = one engine batch of each of the "
-                                   f"{GROUPS} game groups = {GROUPS * args.batch} positions",
+                                   f"{GROUPS} game groups" + (f" x {LANES} lanes" if LANES > 1 else "") +
+                                   f" = {GROUPS * LANES * args.batch} positions",
                        "batch_per_gpu": args.batch, "concurrent_games_per_gpu": GROUPS * args.batch,
-                       "game_groups_per_gpu": GROUPS, "host_threads_per_gpu": threads,
+                       "game_groups_per_gpu": GROUPS, "lanes_per_group": LANES, "host_threads_per_gpu": threads,
                        "host_cpus_of_rank0": [cpus[0], cpus[-1]] if cpus else None,
                        "ladder_node_budget": args.ladder_budget,
                        "parallelism": f"games sharded x{n_gpus}, no collective"},

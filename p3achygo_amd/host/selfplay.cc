@@ -780,7 +780,7 @@ void p3host_selfplay_set_groups(int n) { g_num_groups = n < 1 ? 1 : (n > 8 ? 8 :
 // search may wait for results at once.  1 / 1 (the default): host and GPU alternate within a group.  2 / up to 4:
 // one group overlaps its host work with its own forward passes (BASELINE configs[2] as stated: 1024 games, batch 1024).
 void p3host_selfplay_set_lanes(int lanes, int max_inflight) {
-  g_num_lanes = lanes < 1 ? 1 : (lanes > 2 ? 2 : lanes);
+  g_num_lanes = lanes < 1 ? 1 : (lanes > 4 ? 4 : lanes);
   g_max_inflight = max_inflight < 1 ? 1 : (max_inflight > GumbelSearch::kMaxInflight ? GumbelSearch::kMaxInflight : max_inflight);
 }
 // > 0: subsequent p3host_selfplay_run calls measure exactly `batches` engine batches (bench.py's
@@ -980,8 +980,11 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
   // completion instants, seconds since t0 (guarded by clock_mu): of the counted batches, or (by_rounds) of the anchor's
   std::vector<double> done_at;
   std::atomic<bool> failed{false};
+  std::atomic<long> phase_hist_store[16];
+  for (auto& c : phase_hist_store) c.store(0);
+  std::atomic<long>* phase_hist = getenv("P3HOST_PHASE_STATS") ? phase_hist_store : nullptr;
   for (int h = 0; h < NG; ++h) {
-    halves[h].adv_left = g_advance_limit;
+    halves[h].adv_left = g_advance_limit * NL;   // (a game in its opening has one evaluation in flight: every NL-th batch)
     halves[h].prev = group_totals(halves[h]);
   }
   for (int h = 0; h < NG; ++h)
@@ -1010,6 +1013,10 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
             L.in_opening = L.past_opening < (long)H.games.size();
           }
           L.host_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
+          if (phase_hist) {   // P3HOST_PHASE_STATS=1: how long the host phases take (a slow game holds up its whole group)
+            const int b = std::min(15, (int)(L.host_seconds * 1e3));
+            ++phase_hist[b];
+          }
           {
             std::lock_guard<std::mutex> tl(H.turn_mu);
             H.turn = (l + 1) % NL;
@@ -1076,6 +1083,11 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     }
   for (auto& H : halves)
     for (auto& L : H.lanes) L->driver.join();
+  if (phase_hist) {
+    std::fprintf(stderr, "host phases by duration (ms, last bin >= 15):");
+    for (int b = 0; b < 16; ++b) std::fprintf(stderr, " %ld", phase_hist[b].load());
+    std::fprintf(stderr, "\n");
+  }
   int rc = 0;
   for (auto& H : halves)
     if (!H.ok) {

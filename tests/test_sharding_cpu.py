@@ -83,7 +83,7 @@ def test_bench_gpus_flag_starts_that_many_ranks(built):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--null-engine", "--steps", "7", "--warmup", "2",
-           "--batch", "16", "--groups", "3"]
+           "--batch", "16", "--groups", "3", "--lanes", "1"]
     one = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert one.returncode == 0, one.stderr[-2000:]
     a = json.loads(one.stdout.strip().splitlines()[-1])

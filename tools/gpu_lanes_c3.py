@@ -11,8 +11,10 @@ netspec.save_p3w(path, cfg, netspec.generate_weights(cfg))
 threads = max(2, min(16, len(os.sched_getaffinity(0))))
 host_api.set_advance_limit(400)
 host_api.set_step_limit(steps)
-for groups, lanes, depth, games in ((1, 1, 1, 1024), (1, 2, 2, 1024), (1, 2, 3, 1024), (1, 2, 4, 1024), (2, 1, 1, 2048),
-                                    (2, 2, 4, 2048), (8, 1, 1, 8192)):
+CASES = ((1, 1, 1, 1024), (1, 2, 2, 1024), (1, 2, 3, 1024), (1, 2, 4, 1024), (2, 1, 1, 2048), (2, 2, 4, 2048), (8, 1, 1, 8192))
+if len(sys.argv) > 2:
+    CASES = tuple(tuple(int(v) for v in a.split(",")) for a in sys.argv[2:])
+for groups, lanes, depth, games in CASES:
     host_api.set_groups(groups)
     host_api.set_lanes(lanes, depth)
     st = host_api.selfplay_run(path, games, threads, 0.0, default_n=32, default_k=5, selected_n=32, selected_k=5,

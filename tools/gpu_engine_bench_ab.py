@@ -15,8 +15,9 @@ pos = np.tile(features.random_positions(64, seed=1, n_games=16), 16)[:1024].copy
 eb = host_api.engine_benchmark(path, pos, 1024, warmup_runs=100, max_rounds=601, device=0)
 print("RESULT avg_run_us %%.1f  positions/s %%.0f  loop positions/s %%.0f" %% (eb.avg_run_us, 1024 / (eb.avg_run_us * 1e-6), eb.positions / eb.loop_seconds), flush=True)
 """
+VARIANTS = (("direct", {}), ("copied", {"P3HIP_NO_DIRECT_RESULTS": "1"}))
 for rnd in range(2):
-    for label, extra in (("direct", {}), ("copied", {"P3HIP_NO_DIRECT_RESULTS": "1"})):
+    for label, extra in VARIANTS:
         env = dict(os.environ); env.pop("P3HIP_NO_DIRECT_RESULTS", None); env.update(extra)
         r = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, capture_output=True, text=True, timeout=300)
         print(label, (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)

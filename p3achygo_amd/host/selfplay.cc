@@ -295,6 +295,10 @@ class GameRunner {
   }
   // the engine's result for the OLDEST request that went to the engine (requests complete in order)
   void DeliverResult(p3hip_result& r) {
+    if (fifo_.empty() || fifo_.front().alias_of) {   // a result nobody asked for: a scheduling bug, not something to search on
+      std::fprintf(stderr, "GameRunner::DeliverResult: no engine request at the head of the queue (%zu in flight)\n", fifo_.size());
+      std::abort();
+    }
     Request e = std::move(fifo_.front());
     fifo_.pop_front();
     UnapplySymmetry(e.sym, &r);   // nn_interface.h:263-288

@@ -26,7 +26,8 @@ process, one engine set, one HIP stream set per device; no data-path collective)
 touches the GPU); under torch.distributed.run it checks N against WORLD_SIZE.
 
 Secondary figures in the same JSON line:
-  engine_only  — forward pass alone over a resident batch (no host, no PCIe);
+  engine_only  — forward pass alone over a resident batch (no host, no PCIe), with the shader clock and socket power
+                 amdsmi reports while it loops (`chip_during_loop`);
   engine_benchmark — the reference's nn::Benchmark loop (benchmark_engine.cc:77-108) from C++ over the C ABI;
   as_stated_c3 — BASELINE configs[2] as written: ONE group of 1024 games, batch 1024, the group filling two engine
                  batches in turn with up to 4 playouts of a game's search in flight (round 4: same games, DESIGN.md
@@ -361,12 +362,26 @@ def main():
         eng.forward_resident(args.batch)
     eng.sync()
     sharding.barrier(shard)
+    sampler = None
+    if rank == 0:   # shader clock and socket power beside the loop (a side thread reading amdsmi every 20 ms)
+        try:
+            from p3achygo_amd.power_sampler import PowerSampler
+            sampler = PowerSampler(local_rank)
+            sampler.start()
+        except Exception:   # noqa: BLE001
+            sampler = None
     t0 = time.perf_counter()
     for _ in range(args.engine_steps):
         eng.forward_resident(args.batch)
     eng.sync()
     torch.cuda.synchronize()
     dt_e = sharding.max_over_ranks(shard, time.perf_counter() - t0)
+    power = None
+    if sampler is not None:
+        try:
+            power = sampler.stop()
+        except Exception:   # noqa: BLE001
+            power = None
     sharding.barrier(shard)
     total_flops, conv3_flops = eng.flops_per_position()
 
@@ -486,7 +501,10 @@ def main():
                               "ms_per_step": dt_e / args.engine_steps * 1e3,
                               "what": "forward pass over a resident batch: no host, no PCIe",
                               "full_net_tflops": eng_pps * total_flops / 1e12,
-                              "conv3x3_mfma_frac": eng_pps * conv3_flops / 1e12 / (PEAK_FP16_MFMA_TFLOPS * n_gpus)}
+                              "conv3x3_mfma_frac": eng_pps * conv3_flops / 1e12 / (PEAK_FP16_MFMA_TFLOPS * n_gpus),
+                              # the chip's state while this loop ran (rank 0's GPU): the forward pass sits on the socket power
+                              # cap, and the clock the chip grants under it (2.0-2.2 GHz of 2.4) is in every number of this line
+                              "chip_during_loop": power}
         out.update(extras)
         # self-check: a step cannot be shorter than the ONE trunk launch every batch must execute
         if roof and roof.get("launch_ms") and roof.get("kernel", "").startswith("k_block"):

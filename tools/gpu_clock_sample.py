@@ -10,39 +10,7 @@ from p3achygo_amd import engine, features, netspec
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
 
 
-class Sampler:
-    def __init__(self):
-        self.kind, self.h = None, None
-        try:
-            import amdsmi
-            amdsmi.amdsmi_init()
-            self.smi = amdsmi
-            self.h = amdsmi.amdsmi_get_processor_handles()[0]
-            self.read()
-            self.kind = "amdsmi"
-        except Exception as e:  # noqa: BLE001
-            print("amdsmi unavailable:", repr(e)[:200], flush=True)
-            self.kind = "sysfs"
-            self.hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
-
-    def read(self):
-        if self.kind != "sysfs":
-            s = self.smi
-            clk = s.amdsmi_get_clock_info(self.h, s.AmdSmiClkType.GFX)
-            pw = s.amdsmi_get_power_info(self.h)
-            p = pw.get("current_socket_power", pw.get("average_socket_power"))
-            return float(clk.get("clk", clk.get("cur_clk", 0))), float(p if isinstance(p, (int, float)) else 0)
-        f = p = 0.0
-        for h in self.hw[:1]:
-            try:
-                f = int(open(h + "/freq1_input").read()) / 1e6
-                p = int(open(h + "/power1_average").read()) / 1e6
-            except OSError:
-                try:
-                    p = int(open(h + "/power1_input").read()) / 1e6
-                except OSError:
-                    pass
-        return f, p
+from p3achygo_amd.power_sampler import PowerSampler as Sampler   # noqa: E402
 
 
 smp = Sampler()

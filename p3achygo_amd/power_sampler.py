@@ -48,8 +48,25 @@ class PowerSampler:
                     pass
         return f, p
 
+    _RESIDENCIES = ("ppt", "socket_thm", "vr_thm", "hbm_thm", "prochot")
+
+    def residencies(self):
+        """The firmware's limiter residency accumulators (gpu_metrics): ticks of its accumulation counter during which the
+        package power limit (ppt) / a thermal limit / PROCHOT held the clocks down; None when not reported."""
+        if self.kind != "amdsmi":
+            return None
+        try:
+            m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
+            out = {"ticks": m["accumulation_counter"]}
+            for k in self._RESIDENCIES:
+                out[k] = m[k + "_residency_acc"]
+            return out if all(isinstance(v, int) for v in out.values()) else None
+        except Exception:   # noqa: BLE001
+            return None
+
     def start(self, period_s: float = 0.02):
         self._samples, self._stop = [], False
+        self._res0 = self.residencies()
 
         def loop():
             while not self._stop:
@@ -67,11 +84,18 @@ class PowerSampler:
         self._stop = True
         if self._th:
             self._th.join()
+        res1 = self.residencies()
         s = [x for x in self._samples[len(self._samples) // 4:] if x[0] > 0 or x[1] > 0]
         if not s:
             return None
         clk = [x[0] for x in s]
         pw = [x[1] for x in s]
-        return {"sampler": self.kind, "samples": len(s), "gfx_clock_mhz_mean": sum(clk) / len(clk), "gfx_clock_mhz_min": min(clk),
-                "gfx_clock_mhz_max": max(clk), "socket_power_w_mean": sum(pw) / len(pw), "socket_power_w_max": max(pw),
-                "socket_power_cap_w": self.cap_w}
+        out = {"sampler": self.kind, "samples": len(s), "gfx_clock_mhz_mean": sum(clk) / len(clk), "gfx_clock_mhz_min": min(clk),
+               "gfx_clock_mhz_max": max(clk), "socket_power_w_mean": sum(pw) / len(pw), "socket_power_w_max": max(pw),
+               "socket_power_cap_w": self.cap_w}
+        r0 = getattr(self, "_res0", None)
+        if r0 and res1 and res1["ticks"] > r0["ticks"]:
+            dt = res1["ticks"] - r0["ticks"]
+            # share of the sampled interval in which each limiter was holding the clocks down (firmware accumulators)
+            out["limiter_residency"] = {k: (res1[k] - r0[k]) / dt for k in self._RESIDENCIES}
+        return out

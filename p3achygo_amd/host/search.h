@@ -661,7 +661,7 @@ class GumbelSearch {
   // IssueNext: an evaluation was requested (eval_game()/eval_color() name it; it stays in flight until Deliver or
   // ResolveBack), nothing can start before a result in flight arrives, or the search is complete
   enum class Issue { kNeedEval, kBlocked, kDone };
-  static constexpr int kMaxInflight = 6;
+  static constexpr int kMaxInflight = 4;   // (6 measured no better than 4, profiles/r04_lanes_c3_more_lanes.txt; each costs a Position per game)
 
   // `game`, `pool`, `prob` must outlive the search.  `root` must belong to `pool`.
   void Begin(Game* game, NodePool* pool, TreeNode* root, Color color, const GumbelParams& p,

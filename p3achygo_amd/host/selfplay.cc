@@ -314,7 +314,11 @@ class GameRunner {
   }
   // where the scheduler put the request TryAdvance just returned, and the slot of the oldest request if it went
   // to `lane` (-1 otherwise)
-  void SetBackSlot(int lane, int slot) { fifo_.back().lane = lane; fifo_.back().slot = slot; }
+  void SetBackSlot(int lane, int slot) { fifo_.back().lane = lane; fifo_.back().slot = slot; unloaded_ = false; }
+  // the request TryAdvance just returned could not be loaded (the batch had gone): it waits, in the scheduler's feature
+  // buffer of this game, for the next host phase; nothing else may be requested before it is loaded
+  void MarkUnloaded() { unloaded_ = true; }
+  bool unloaded() const { return unloaded_; }
   int FrontSlot(int lane) const {
     return !fifo_.empty() && !fifo_.front().alias_of && fifo_.front().lane == lane ? fifo_.front().slot : -1;
   }
@@ -414,6 +418,7 @@ class GameRunner {
       fork_.reset(new ForkManager(cfg_.fork_params, cfg_.reuse, prob_, /*started_from_forced_search=*/!is_fresh_game));
     forking_ = false;
     fifo_.clear();
+    unloaded_ = false;
     cache_.Clear();
     if (game_->IsGameOver() || game_->num_moves() >= cfg_.max_moves) {
       // A restart state can already be finished (a fork whose alternative move was the second
@@ -611,6 +616,7 @@ class GameRunner {
   bool use_puct_fast_search_ = false, force_full_search_first_move_ = false;
   bool forking_ = false;
   std::deque<Request> fifo_;   // evaluation requests in flight, oldest first
+  bool unloaded_ = false;
   std::unique_ptr<ForkManager> fork_;
   Position side_pos_;
   PreSearch pre_;
@@ -640,37 +646,65 @@ class WorkerPool {
     cv_.notify_all();
     for (auto& t : threads_) t.join();
   }
+  struct Job {
+    std::function<void(int)> fn;
+    int total = 0, next = 0, unfinished = 0;   // guarded by the pool's mutex
+    std::condition_variable done_cv;
+  };
+  using JobRef = std::shared_ptr<Job>;
   // runs fn(i) for i in [0, n) on the pool and returns when all are done; callable from several
   // threads at the same time
   template <class F>
   void ParallelFor(int n, F&& fn) {
     if (n <= 0) return;
-    Job job;
-    job.fn = fn;
-    job.total = n;
-    job.unfinished = n;
-    {
-      std::lock_guard<std::mutex> l(mu_);
-      jobs_.push_back(&job);
+    Wait(Submit(n, std::forward<F>(fn)));
+  }
+  // the same in two steps: the caller may stop waiting (WaitFor) and come back for the rest later (Wait); whatever
+  // fn refers to must then live until that Wait returns
+  template <class F>
+  JobRef Submit(int n, F&& fn) {
+    JobRef job = std::make_shared<Job>();
+    job->fn = std::forward<F>(fn);
+    job->total = n;
+    job->unfinished = n;
+    if (n > 0) {
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        jobs_.push_back(job);
+      }
+      cv_.notify_all();
     }
-    cv_.notify_all();
+    return job;
+  }
+  void Wait(const JobRef& job) {
     std::unique_lock<std::mutex> l(mu_);
-    job.done_cv.wait(l, [&] { return job.unfinished == 0; });
+    job->done_cv.wait(l, [&] { return job->unfinished == 0; });
+  }
+  // waits at most `us` microseconds; the items not finished yet (0: done) and whether every item has been handed out.
+  // (Polls under the mutex between short sleeps: no timed condition-variable wait, whose pthread_cond_clockwait the
+  // ThreadSanitizer of this toolchain does not model.)
+  int WaitFor(const JobRef& job, long us, bool* all_started) {
+    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(us);
+    for (;;) {
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        if (job->unfinished == 0 || std::chrono::steady_clock::now() >= until) {
+          if (all_started) *all_started = job->next == job->total;
+          return job->unfinished;
+        }
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
   }
 
  private:
-  struct Job {
-    std::function<void(int)> fn;
-    int total = 0, next = 0, unfinished = 0;   // guarded by mu_
-    std::condition_variable done_cv;
-  };
   void Loop() {
     std::unique_lock<std::mutex> l(mu_);
     for (;;) {
-      Job* job = nullptr;
+      JobRef job;
       cv_.wait(l, [&] {
         if (stop_) return true;
-        for (Job* j : jobs_)
+        for (const JobRef& j : jobs_)
           if (j->next < j->total) { job = j; return true; }
         return false;
       });
@@ -686,7 +720,7 @@ class WorkerPool {
   std::vector<std::thread> threads_;
   std::mutex mu_;
   std::condition_variable cv_;
-  std::vector<Job*> jobs_;   // oldest first
+  std::vector<JobRef> jobs_;   // oldest first
   bool stop_ = false;
 };
 
@@ -717,6 +751,16 @@ struct Half {
   int turn = 0;
   bool quit = false;
   GameStats prev;              // game counters at the end of the last host phase (host phases only)
+  // Stragglers (two or more lanes): a host phase that is waiting for a last few slow games while the GPU has run dry hands
+  // them over — its batch leaves without them, they finish on the pool (`late`), and the group's next host phase starts by
+  // waiting for them and loads what they asked for into ITS batch.  `settled[g]` = game g's task of the current phase has
+  // ended (its counters may be read); `snap` = every game's counters as last read settled.
+  WorkerPool::JobRef late;
+  std::unique_ptr<std::atomic<uint8_t>[]> settled;
+  std::vector<GameStats> snap;
+  std::vector<uint8_t> snap_past_opening;
+  std::atomic<int> waiting{0};   // lane drivers waiting for their turn (their runs are done: the GPU is about to idle)
+  long handed_over_phases = 0, handed_over_games = 0, phase_no = 0;
   // guarded by the job's clock mutex; read by the caller after the threads have been joined
   bool ok = true, ready = false;
   long warm = 0;
@@ -744,6 +788,8 @@ double g_last_bias_adj = 0;
 int g_num_groups = 2;
 long g_step_limit = 0;   // > 0: the measured region ends after this many engine batches
 int g_num_lanes = 1, g_max_inflight = 1;
+long g_test_slow_us = 0;   // tests: some games sleep this long in some host phases (a stand-in for a slow ladder read-out)
+long g_last_handed_over_phases = 0, g_last_handed_over_games = 0;
 std::vector<uint64_t> g_first_game_digests;   // of the last p3host_selfplay_run, one per game runner
 long g_step_rounds = 0;  // > 0: the measured region is this many ROUNDS (one batch of every group), anchored on one group
 int g_advance_limit = 0;   // > 0: untimed batches per group, at most, to play every game past its raw-policy opening
@@ -803,6 +849,13 @@ void p3host_selfplay_set_step_rounds(long rounds) { g_step_rounds = rounds > 0 ?
 void p3host_selfplay_set_advance_limit(int max_batches) { g_advance_limit = max_batches > 0 ? max_batches : 0; }
 // reuse-buffer insertions and training examples written by the last p3host_selfplay_run
 long p3host_selfplay_last_reuse_added() { return g_last_reuse_added; }
+// tests: every 61st (game, host phase) pair sleeps `us` microseconds before it advances; 0 = off
+void p3host_selfplay_set_test_slow_games(long us) { g_test_slow_us = us > 0 ? us : 0; }
+// of the last p3host_selfplay_run: host phases that let their batch leave without a last few slow games, and those games
+void p3host_selfplay_last_handed_over(long* phases, long* games) {
+  if (phases) *phases = g_last_handed_over_phases;
+  if (games) *games = g_last_handed_over_games;
+}
 // per game runner of the last p3host_selfplay_run (group by group): a digest of its first finished game, 0 if none
 int p3host_selfplay_last_first_game_digests(uint64_t* out, int cap) {
   int n = 0;
@@ -913,46 +966,95 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     }
   }
   WorkerPool pool(num_threads > 0 ? num_threads : 1);
-  for (int h = 0; h < NG; ++h) halves[h].feats.resize(halves[h].games.size());
-
-  auto group_totals = [](const Half& H) {
-    GameStats t;
-    for (auto& g : H.games) {
-      t.moves += g->stats().moves; t.games += g->stats().games;
-      t.evals += g->stats().evals; t.black_wins += g->stats().black_wins;
-      t.cache_hits += g->stats().cache_hits;
-      t.bias_entries_pruned += g->stats().bias_entries_pruned;
-      t.bias_adj_abs_sum += g->stats().bias_adj_abs_sum;
+  for (int h = 0; h < NG; ++h) {
+    Half& H = halves[h];
+    const size_t n = H.games.size();
+    H.feats.resize(n);
+    H.settled.reset(new std::atomic<uint8_t>[n]);
+    H.snap.resize(n);
+    H.snap_past_opening.assign(n, 0);
+    for (size_t g = 0; g < n; ++g) {
+      H.settled[g].store(1);
+      H.snap[g] = H.games[g]->stats();
     }
-    return t;
-  };
+  }
+
   // The host phase of lane `l` of group `h` (the caller holds the group's turn): every game takes its results of
   // the lane's last run, in request order, and advances to its next leaf, which goes into the lane's next batch.
   // With several playouts in flight a game may have nothing to start (its next playout waits for a result of the
   // OTHER lane's batch); the rows such games leave empty go, in a second pass, to games that can start another
   // playout, so the batch stays full.
+  struct PhaseCtl { std::atomic<bool> open{true}; std::atomic<int> loading{0}, delivered{0}; };
+  const long slow_us = g_test_slow_us;
   auto host_phase = [&](int h, int l) {
     Half& H = halves[h];
     Lane& L = *H.lanes[l];
     const int cap = (int)H.games.size();
+    // the previous phase's stragglers first: from here on nothing but this phase touches the group's games
+    if (H.late) { pool.Wait(H.late); H.late.reset(); }
     L.count.store(0);
-    pool.ParallelFor(cap, [&H, &L, l, depth](int g) {
+    auto ctl = std::make_shared<PhaseCtl>();
+    for (int g = 0; g < cap; ++g) H.settled[g].store(0, std::memory_order_relaxed);
+    const long phase_no = H.phase_no++;
+    WorkerPool::JobRef job = pool.Submit(cap, [&H, &L, l, depth, ctl, slow_us, phase_no](int g) {
       GameRunner& G = *H.games[g];
+      // the request in feats[g] goes into this lane's batch — while the phase is open; after that it waits for the next one
+      auto load = [&]() -> bool {
+        ctl->loading.fetch_add(1);
+        const bool open = ctl->open.load();
+        if (open) {
+          const int slot = L.count.fetch_add(1);
+          L.eval->Load(slot, H.feats[g]);
+          G.SetBackSlot(l, slot);
+        } else {
+          G.MarkUnloaded();
+        }
+        ctl->loading.fetch_sub(1);
+        return open;
+      };
       for (int slot; (slot = G.FrontSlot(l)) >= 0;) {
         p3hip_result r;
         L.eval->Get(slot, r);
         G.DeliverResult(r);
       }
-      if (G.TryAdvance(&H.feats[g], depth)) {
-        const int slot = L.count.fetch_add(1);
-        L.eval->Load(slot, H.feats[g]);
-        G.SetBackSlot(l, slot);
-      }
+      ctl->delivered.fetch_add(1);     // this game no longer needs the lane's last results: the lane may run again
+      // a request made by a straggler of the previous phase (after the deliveries: it must not pass for one of this
+      // lane's last batch)
+      const bool ok = !G.unloaded() || load();
+      if (slow_us > 0 && ((uint64_t)g * 2654435761ull + (uint64_t)phase_no * 40503ull) % 61 == 0)   // tests: a slow game
+        std::this_thread::sleep_for(std::chrono::microseconds(slow_us));
+      if (ok && G.TryAdvance(&H.feats[g], depth)) load();
+      H.settled[g].store(1, std::memory_order_release);
     });
+    if (H.lanes.size() > 1) {
+      // Wait for the games — but not for a last few slow ones (an exact ladder read-out can take tens of milliseconds)
+      // once another lane's run has come back, i.e. the GPU has nothing left to do: the batch then leaves without them.
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+        bool all_started = false;
+        const int left = pool.WaitFor(job, 100, &all_started);
+        if (left == 0) break;
+        if (left * 32 <= cap && all_started && ctl->delivered.load() == cap && H.waiting.load() > 0 &&
+            std::chrono::steady_clock::now() - t0 >= std::chrono::milliseconds(1)) {
+          ctl->open.store(false);
+          while (ctl->loading.load() > 0) std::this_thread::yield();   // a load that saw the phase open completes
+          H.late = job;
+          ++H.handed_over_phases;
+          H.handed_over_games += left;
+          break;
+        }
+      }
+    } else {
+      pool.Wait(job);
+    }
     if (depth > 1 && L.count.load() < cap) {
+      // rows left empty (games that wait for a result of the other lane's batch, stragglers handed over) go to games that
+      // can start another playout
       std::atomic<int> spare{cap - L.count.load()};
       pool.ParallelFor(cap, [&H, &L, &spare, l, depth](int g) {
+        if (!H.settled[g].load(std::memory_order_acquire)) return;   // a straggler: still at work on the pool
         GameRunner& G = *H.games[g];
+        if (G.unloaded()) return;   // a straggler that has just ended with a request: feats[g] holds it for the next phase
         while (spare.load(std::memory_order_relaxed) > 0) {
           if (spare.fetch_sub(1) <= 0) { spare.fetch_add(1); break; }
           if (!G.TryAdvance(&H.feats[g], depth)) { spare.fetch_add(1); break; }
@@ -962,6 +1064,23 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
         }
       });
     }
+    // counters of the games whose tasks have ended (a straggler's are read when it has)
+    for (int g = 0; g < cap; ++g)
+      if (H.settled[g].load(std::memory_order_acquire)) {
+        H.snap[g] = H.games[g]->stats();
+        H.snap_past_opening[g] = H.games[g]->past_opening();
+      }
+  };
+  auto group_totals = [](const Half& H) {
+    GameStats t;
+    for (const GameStats& g : H.snap) {
+      t.moves += g.moves; t.games += g.games;
+      t.evals += g.evals; t.black_wins += g.black_wins;
+      t.cache_hits += g.cache_hits;
+      t.bias_entries_pruned += g.bias_entries_pruned;
+      t.bias_adj_abs_sum += g.bias_adj_abs_sum;
+    }
+    return t;
   };
 
   // Every group runs on its own: advance batches (until its games are past their openings), warm-up
@@ -999,12 +1118,14 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
         for (;;) {
           {
             std::unique_lock<std::mutex> tl(H.turn_mu);
+            H.waiting.fetch_add(1);
             H.turn_cv.wait(tl, [&] { return H.turn == l || H.quit; });
+            H.waiting.fetch_sub(1);
             if (H.quit) break;
           }
           const auto a0 = std::chrono::steady_clock::now();
           host_phase(h, l);
-          {   // the games are quiescent until the turn is passed on: their counters can be read
+          {   // the counters as the host phase left them (games handed over as stragglers: as of their last settled phase)
             const GameStats now = group_totals(H);
             L.delta.moves = now.moves - H.prev.moves; L.delta.games = now.games - H.prev.games;
             L.delta.evals = now.evals - H.prev.evals; L.delta.black_wins = now.black_wins - H.prev.black_wins;
@@ -1013,7 +1134,7 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
             L.delta.bias_adj_abs_sum = now.bias_adj_abs_sum - H.prev.bias_adj_abs_sum;
             H.prev = now;
             L.past_opening = 0;
-            for (auto& g : H.games) L.past_opening += g->past_opening();
+            for (uint8_t po : H.snap_past_opening) L.past_opening += po;
             L.in_opening = L.past_opening < (long)H.games.size();
           }
           L.host_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
@@ -1087,6 +1208,12 @@ int p3host_selfplay_run(const char* engine_lib, const char* weights, int device,
     }
   for (auto& H : halves)
     for (auto& L : H.lanes) L->driver.join();
+  g_last_handed_over_phases = g_last_handed_over_games = 0;
+  for (auto& H : halves) {
+    if (H.late) { pool.Wait(H.late); H.late.reset(); }   // before the games go away
+    g_last_handed_over_phases += H.handed_over_phases;
+    g_last_handed_over_games += H.handed_over_games;
+  }
   if (phase_hist) {
     std::fprintf(stderr, "host phases by duration (ms, last bin >= 15):");
     for (int b = 0; b < 16; ++b) std::fprintf(stderr, " %ld", phase_hist[b].load());

@@ -274,6 +274,24 @@ def set_lanes(lanes: int = 1, max_inflight: int = 1) -> None:
     L.p3host_selfplay_set_lanes(int(lanes), int(max_inflight))
 
 
+def set_test_slow_games(us: int) -> None:
+    """Tests: every 61st (game, host phase) pair of subsequent selfplay_run calls sleeps `us` microseconds before it
+    advances — a stand-in for a slow exact ladder read-out; 0 = off."""
+    L = lib()
+    L.p3host_selfplay_set_test_slow_games.argtypes = [C.c_long]
+    L.p3host_selfplay_set_test_slow_games(int(us))
+
+
+def last_handed_over():
+    """(host phases, games) of the last selfplay_run whose batch left without a last few slow games (two or more lanes:
+    the stragglers finish on the pool and load into the group's next batch)."""
+    L = lib()
+    L.p3host_selfplay_last_handed_over.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    a, b = C.c_long(), C.c_long()
+    L.p3host_selfplay_last_handed_over(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 def last_first_game_digests() -> np.ndarray:
     """Per game runner of the last selfplay_run: a digest of its first finished game (moves and score), 0 if none."""
     L = lib()

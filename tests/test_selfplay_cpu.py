@@ -681,12 +681,45 @@ def test_two_lanes_of_one_group_play_the_same_games(host):
     try:
         base, fill = run(1, 1, 560)
         assert fill == 1.0 and (base != 0).all()
-        for depth, steps, min_fill in ((1, 1120, 0.49), (2, 800, 0.7), (4, 700, 0.88)):
+        for depth, steps, min_fill in ((1, 1120, 0.49), (2, 800, 0.7), (4, 700, 0.85)):
             got, fill = run(2, depth, steps)
             both = (got != 0) & (base != 0)
             assert both.sum() >= 44 and (got[both] == base[both]).all(), depth
             assert fill >= min_fill, (depth, fill)
     finally:
+        host.set_lanes(1, 1)
+        host.set_step_limit(0)
+        host.set_groups(2)
+        host.set_policy()
+
+
+def test_a_batch_does_not_wait_for_a_last_few_slow_games(host):
+    """Two lanes: a host phase whose last few games are slow (an exact ladder read-out can take tens of milliseconds)
+    lets its batch leave without them once another lane's run has come back; the stragglers finish on the pool, the
+    group's next host phase waits for them first and loads what they asked for into ITS batch.  With every 61st
+    (game, phase) pair asleep for 2 ms nearly every phase hands games over — and every game runner still plays the
+    same first game as the one-lane, one-at-a-time schedule, at every depth."""
+    host.set_policy(init_state_sampling=False)
+    host.set_groups(1)
+
+    def run(lanes, depth, steps, slow_us):
+        host.set_lanes(lanes, depth)
+        host.set_step_limit(steps)
+        host.set_test_slow_games(slow_us)
+        host.selfplay_run(None, 48, 4, 0.0, default_n=16, default_k=4, selected_n=16, selected_k=4, max_moves=24,
+                          warmup_batches=1, seed=5, engine_lib="hash")
+        return host.last_first_game_digests(), host.last_handed_over()
+
+    try:
+        base, (phases0, games0) = run(1, 1, 560, 0)
+        assert (base != 0).all() and phases0 == 0 and games0 == 0          # one lane never hands over
+        for depth, steps in ((4, 800), (2, 900), (1, 1200)):
+            got, (phases, games) = run(2, depth, steps, 2000)
+            both = (got != 0) & (base != 0)
+            assert both.sum() >= 40 and (got[both] == base[both]).all(), depth
+            assert phases >= steps // 4 and games >= phases, (depth, phases, games)
+    finally:
+        host.set_test_slow_games(0)
         host.set_lanes(1, 1)
         host.set_step_limit(0)
         host.set_groups(2)

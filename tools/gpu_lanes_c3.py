@@ -22,4 +22,5 @@ for groups, lanes, depth, games in CASES:
     d = host_api.last_first_game_digests()
     print(f"groups {groups} lanes {lanes} depth {depth} games {games}: {st.positions / st.seconds:9.0f} positions/s  "
           f"fill {st.positions / max(st.batches, 1) / 1024:.3f}  batches {st.batches}  ms/batch {1e3 * st.seconds / st.batches:.3f}  "
-          f"host share {st.host_seconds / st.seconds:.3f}  evals/move {st.positions / max(st.moves, 1):.2f}", flush=True)
+          f"host share {st.host_seconds / st.seconds:.3f}  evals/move {st.positions / max(st.moves, 1):.2f}  "
+          f"handed over (phases, games) {host_api.last_handed_over()}", flush=True)

@@ -909,3 +909,33 @@ def test_launch_graph_with_the_nn_cache_never_replays_the_other_feature_buffer(b
     got = np.stack([eng.get_raw(i) for i in range(B)])
     assert np.array_equal(got, wantB)
     eng.close()
+
+
+def test_bench_line_keeps_its_contract_and_its_self_checks(built):
+    """bench.py's one JSON line on the GPU (a short run: 8 rounds, no CPU baseline, no counter passes): the driver's keys,
+    a steady-state headline (per-batch time not below the trunk launch's own time, value not above what the forward pass
+    alone does by more than the streams' overlap allows), the roofline object, and the chip's state beside the engine-only leg."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-pmc", "--no-extras", "--engine-steps", "60"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["unit"] == "positions/s" and d["dtype"] == "f16"
+    assert "workload" in d["config"] and d["config"]["game_groups_per_gpu"] == 8
+    assert d["engine_batches_completed"] >= 8 * 8 - 8 and d["mean_batch_fill"] > 0.99
+    roof = d["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0.2 < roof["frac"] < 0.6
+    assert d["window_artifact"] is False and d["ms_per_batch"] >= 0.98 * roof["launch_ms"]
+    assert d["value"] <= 1.06 * d["engine_only"]["value"]          # a self-play line cannot beat its own forward pass
+    chip = d["engine_only"]["chip_during_loop"]
+    if chip is not None:                                            # amdsmi present: clock, power and limiter residencies
+        assert 500 < chip["gfx_clock_mhz_mean"] < 3000 and chip["socket_power_w_mean"] > 100

@@ -60,6 +60,7 @@ DEFAULT_GROUPS = GROUPS = 8          # game groups per GPU: forward passes of th
                                      # pass one long launch: 4 / 6 / 8 groups 225 / 237 / 241 k with 241 k engine-only, and the driver's
                                      # 20-step window steadier with eight: 239-242 k against 209-242 k)
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 PF
+MEASURED_PIPE_CEILING_TFLOPS = 1869.0   # round 4, profiles/r04_mfma_energy_probe.txt: pure 16x16x32 MFMA stream on real-like values
 LADDER_BUDGET = 0       # ladder read-out work bound of the host: 0 = the reference's exact read-out (default)
 
 
@@ -396,7 +397,12 @@ def main():
                 "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP16_MFMA_TFLOPS,
                 "traffic": prof["traffic_bytes_per_launch"] if prof else None,   # HBM bytes per launch (recorded)
-                "launch_ms": ms, "algorithmic_flops_per_launch": flops_launch}
+                "launch_ms": ms, "algorithmic_flops_per_launch": flops_launch,
+                # information beside the contract's `peak`: what a stream of nothing but v_mfma_f32_16x16x32_f16 on register
+                # operands with this net's value statistics holds on this pool under the socket's power limit
+                # (tools/gpu_mfma_energy_probe.py, profiles/r04_mfma_energy_probe.txt: 0.75 of the peak; 0.98 on zeros)
+                "matrix_pipe_ceiling_measured": {"tflops": MEASURED_PIPE_CEILING_TFLOPS,
+                                                 "frac_of_it": achieved / MEASURED_PIPE_CEILING_TFLOPS}}
         if prof:
             roof["algorithmic_bytes_per_launch"] = prof["algorithmic_bytes_per_launch"]
             roof["traffic_source"] = "recorded: " + prof["source"]
